@@ -1,0 +1,236 @@
+"""
+Benchmark of the cosmos SVI hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): cosmos K=2, 400 AOIs x 1000 frames, P=14, synthetic data with
+the law of tapqir/utils/simulate.py and the reference test-suite parameters; one *step* = one
+complete SVI update (guide draws -> ELBO -> gradients -> dense Adam) over the full batch held
+by the rank.  With N ranks every rank holds its own 400 x 1000 shard (AOI-sharded, weak
+scaling) and the only communication is one all-reduce of the 6 cross-unit sums per step.
+
+Prints ONE JSON line (rank 0).  `value` = AOI-frames/s over all ranks; also reported:
+ELBO steps/s, the reference's default-minibatch operating point, the HBM roofline of the fused
+spot-render + log-prob kernel (HIP-event timing on its own stream) and the CPU baseline
+(oracle = dense-torch float64 restatement, timed on this box's host cores).
+"""
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X nominal HBM3E bandwidth (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def fwd_bytes_per_unit(K, P):
+    """tile + xy + (h,w,x,y per spot; b) + 2^K outputs, fp32."""
+    return 4 * P * P + 8 + 4 * (4 * K + 1) + 4 * 2**K
+
+
+def step_bytes_per_unit(K, P):
+    """fused step with dense Adam, gradients never round-tripping."""
+    return 4 * P * P + 8 + 6 * 4 * (8 * K + 2)
+
+
+def time_pixel_kernel(eng, launches, backward):
+    """Average duration of the fused render+log-prob kernel, HIP events on its launch stream."""
+    from tapqir_amd import _lib
+
+    a = eng.make_args()
+    K, M = eng.K, 1 << eng.K
+    B = eng.Nt * eng.F * eng.C
+    k = _lib.KsmognArgs()
+    p = _lib.ptr
+    k.images, k.xy, k.ndx, k.fdx = p(eng.images), p(eng.xy), None, None
+    lat = eng.lat
+    f = lambda row: lat.data_ptr() + 4 * row * B
+    k.background, k.height, k.width, k.x, k.y = f(0), f(1), f(1 + K), f(1 + 2 * K), f(1 + 3 * K)
+    k.gain = eng.globals.data_ptr()
+    k.offset_samples, k.offset_logits = p(eng.offset_samples), p(eng.offset_logits)
+    k.gout, k.m_logit, k.aoi_mask = None, p(eng.params), p(eng.mask)
+    pix = eng.pix
+    g = lambda row: pix.data_ptr() + 4 * row * B
+    k.ll = g(0)
+    if backward:
+        k.g_background, k.g_gain = g(M), g(M + 1)
+        k.g_height, k.g_width, k.g_x, k.g_y = g(M + 2), g(M + 2 + K), g(M + 2 + 2 * K), g(M + 2 + 3 * K)
+    k.m_kstride = B
+    k.nb, k.fb, k.C, k.F, k.P, k.K, k.O = eng.Nt, eng.F, eng.C, eng.F, eng.P, K, eng.O
+    k.scale = 1.0
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    for _ in range(3):
+        _lib.check(eng.lib.tq_ksmogn_log_prob(C.byref(k), sp), "tq_ksmogn_log_prob")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(launches):
+        eng.lib.tq_ksmogn_log_prob(C.byref(k), sp)
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / launches * 1e-3  # seconds
+
+
+def cpu_baseline(data, K, nb, fb, steps=3, warmup=1):
+    """Oracle (dense torch float64 = the tensor program Pyro would run) on the host cores."""
+    from oracle.cosmos import CosmosOracle, OracleData
+
+    torch.set_num_threads(os.cpu_count())
+    od = OracleData(data.images[:nb, :fb].cpu(), data.xy[:nb, :fb].cpu(), data.is_ontarget[:nb].cpu(),
+                    data.offset.samples.cpu(), data.offset.weights.cpu())
+    o = CosmosOracle(od, K=K)
+    o.init_parameters()
+    o.make_optim(lr=0.005)
+    nd, fd = torch.arange(nb), torch.arange(fb)
+    ts = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
+        o.step(nd, fd)
+        if it >= warmup:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": nb * fb / med, "unit": "AOI-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle dense-torch float64 full SVI step, nb={nb} x fb={fb} units of the same data, "
+                      f"median of {steps} steps after {warmup} warm-up ({med:.2f} s/step = {1 / med:.3f} steps/s)",
+            "steps_per_sec_at_sample": 1 / med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--aois", type=int, default=400)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--K", type=int, default=2)
+    ap.add_argument("--P", type=int, default=14)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--offsets", default="sim", choices=["sim", "hist"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from tapqir_amd.models.engine import CosmosEngine
+    from tapqir_amd.utils.dataset import CosmosDataset
+    from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+    class _M:  # minimal "model" for simulate(): K and device
+        K, device = args.K, dev
+
+    N, F, K, P = args.aois, args.frames, args.K, args.P
+    data = simulate(_M, N, F, 1, P, seed=1000 + rank, params=TEST_PARAMS)
+    if args.offsets == "hist":
+        s = torch.arange(70.0, 120.0)
+        w = torch.minimum(s - 69.0, 120.0 - s)
+        data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s, offset_weights=w / w.sum())
+    eng = CosmosEngine(data, K=K, device=dev, seed=7, n_offset=rank * N, Nt_global=world * N)
+    # initial parameter values of the reference (cosmos.py:471-598)
+    from tapqir_amd.models.cosmos import initial_values
+
+    eng.layout.set_constrained(eng.params, initial_values(eng, data))
+
+    allreduce = None
+    if world > 1:
+        def allreduce(t):
+            dist.all_reduce(t)
+
+    def run(n, ndx=None, fdx=None):
+        for _ in range(n):
+            eng.step(ndx, fdx, allreduce=allreduce)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- headline: full-batch steps -----------------------------------------------------------------
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    units_per_step = world * N * F
+    value = units_per_step / (dt / args.steps)
+    elbo = float(eng.elbo_out[0])
+    assert torch.isfinite(eng.params).all(), "non-finite parameters after the timed steps"
+
+    out = {
+        "metric": "cosmos SVI AOI-frames/s (= ELBO steps/s x nb x fb), K=2 P=14 full batch",
+        "value": value, "unit": "AOI-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cosmos K={K}, {N} AOIs x {F} frames per GPU, P={P}, full-batch SVI step "
+                               f"(sample guide, ELBO, gradients, dense Adam); offsets={args.offsets} (O={eng.O} after merging)",
+                   "nb": N, "fb": F, "aoi_sharding": f"{world} x {N} AOIs"},
+        "elbo_steps_per_sec": 1e3 / ms_per_step,
+        "final_elbo": elbo,
+    }
+
+    if rank == 0:
+        # ---- reference default minibatch operating point (main.py:1429-1430): nb=10, fb=512 ----------
+        if world == 1:
+            nb, fb = min(10, N), min(512, F)
+            g = torch.Generator(device="cpu").manual_seed(0)
+            idx = [(torch.randperm(N, generator=g)[:nb], torch.randperm(F, generator=g)[:fb]) for _ in range(20)]
+            for nd, fd in idx[:3]:
+                eng.step(nd, fd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for nd, fd in idx:
+                eng.step(nd, fd)
+            torch.cuda.synchronize()
+            mb = (time.perf_counter() - t0) / len(idx)
+            out["minibatch_10x512"] = {"ms_per_step": mb * 1e3, "steps_per_sec": 1 / mb,
+                                       "aoi_frames_per_sec": nb * fb / mb}
+        # ---- roofline of the dominant kernel -----------------------------------------------------------
+        t_fb = time_pixel_kernel(eng, 20, backward=True)
+        t_f = time_pixel_kernel(eng, 20, backward=False)
+        bpu = fwd_bytes_per_unit(K, P)
+        ach = N * F * bpu / t_fb / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "tq_ksmogn_kernel<K,one_offset,bwd> (fused render + log-prob + pathwise grads)",
+                           "bytes_per_unit": bpu, "units_per_launch": N * F, "avg_launch_ms": t_fb * 1e3,
+                           "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": N * F * bpu / t_f / 1e9,
+                                            "frac": N * F * bpu / t_f / 1e9 / HBM_PEAK_GBS},
+                           "whole_step": {"bytes_per_unit": step_bytes_per_unit(K, P),
+                                          "achieved": N * F * step_bytes_per_unit(K, P) / (ms_per_step * 1e-3) / 1e9,
+                                          "frac": N * F * step_bytes_per_unit(K, P) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(data, K, min(10, N), min(512, F))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

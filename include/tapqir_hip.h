@@ -1,0 +1,171 @@
+/* tapqir_hip.h -- C ABI of libtapqir_hip.so, the MI355X (gfx950) implementation of the
+ * cosmos SVI hot path of Tapqir.
+ *
+ * The reference has no FFI for this path (it is 100 % Python): the seam is
+ * the Python class contract tapqir.models.Model / tapqir.distributions.KSMOGN.  Each entry
+ * point below names the reference code it replaces; the Python host (tapqir_amd/) binds them
+ * through ctypes (INTEGRATION.md shows the stub a maintainer would add to the reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller, contiguous, row-major, float32
+ *     unless stated; nothing is allocated, freed or synchronised inside the library
+ *   - every call is asynchronous on the caller's `stream` (a hipStream_t passed as void*)
+ *   - return value: 0 = launched, nonzero = TQ_ERR_*; tq_last_error() gives the text
+ *   - "unit" = one (AOI n, frame f, channel c) image of P x P pixels.  Minibatch units are
+ *     numbered i = (a * fb + b) * C + c with n = ndx[a], f = fdx[b] (ndx/fdx may be NULL =
+ *     identity); B = nb * fb * C.  Dataset-sized arrays use u = (n * F + f) * C + c.
+ *   - spot arrays are K-major: [K][B] (minibatch) or [K][Nt*F*C] (dataset), as the reference's
+ *     (K, Nt, F, Q) parameters (tapqir/models/cosmos.py:481-598)
+ *   - enumerated spot-presence combinations are indexed mi in [0, 2^K), bit k of mi = m_k
+ */
+#ifndef TAPQIR_HIP_H
+#define TAPQIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TQ_OK 0
+#define TQ_ERR_ARG 1     /* invalid argument (shape, NULL pointer, unsupported K/P) */
+#define TQ_ERR_LAUNCH 2  /* hipLaunch failed (text in tq_last_error) */
+
+#define TQ_MAX_K 4
+#define TQ_MAX_P 32
+
+int tq_version(void);
+const char* tq_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * KSMOGN image likelihood, forward and (optionally) backward in one pass.
+ * Replaces: tapqir/distributions/ksmogn.py:146-238 (gaussians -> image -> concentration ->
+ * log_prob; the KeOps Genred LogSumExp of 188-216) + tapqir/distributions/util.py:15-64
+ * (gaussian_spots) + their autograd backward.
+ *
+ *   ll[mi][i] = sum_pixels log sum_o w_o Gamma(D - delta_o; (b + sum_{k in mi} spot_k)/g, 1/g)
+ *
+ * If the g_* outputs are non-NULL the kernel also returns the gradient of
+ *   sum_mi gout[mi][i] * ll[mi][i]
+ * with respect to background, height, width, x, y (per unit) and gain (per-unit partials,
+ * to be summed by the caller).  The upstream weights are either given (`gout`) or built in
+ * the kernel as the Dice weights of the cosmos guide:
+ *   gout[mi][i] = scale * mask[n] * prod_k (m_k ? sigmoid(u_k) : sigmoid(-u_k)),
+ *   u_k = m_logit[k * m_kstride + u]   (unconstrained `m_probs`, cosmos.py:419-424).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* images;         /* (Nt, F, C, P, P) */
+  const float* xy;             /* (Nt, F, C, 2) target locations (x, y) */
+  const int32_t* ndx;          /* [nb] AOI indices or NULL */
+  const int32_t* fdx;          /* [fb] frame indices or NULL */
+  const float* background;     /* [B]    sampled background b */
+  const float* height;         /* [K][B] sampled h */
+  const float* width;          /* [K][B] sampled w */
+  const float* x;              /* [K][B] sampled x */
+  const float* y;              /* [K][B] sampled y */
+  const float* gain;           /* [1]    sampled gain g (device scalar) */
+  const float* offset_samples; /* [O] */
+  const float* offset_logits;  /* [O] log weights */
+  const float* gout;           /* [2^K][B] upstream weights, or NULL */
+  const float* m_logit;        /* (K, Nt, F, C) unconstrained m_probs, used when gout == NULL */
+  const uint8_t* aoi_mask;     /* [Nt] or NULL (all ones) */
+  float* ll;                   /* [2^K][B] out */
+  float* g_background;         /* [B]    out or NULL (forward only) */
+  float* g_height;             /* [K][B] out */
+  float* g_width;              /* [K][B] out */
+  float* g_x;                  /* [K][B] out */
+  float* g_y;                  /* [K][B] out */
+  float* g_gain;               /* [B]    out: per-unit partial of d/d gain */
+  int64_t m_kstride;           /* = Nt*F*C */
+  int32_t nb, fb, C, F;        /* minibatch and dataset geometry */
+  int32_t P, K, O;
+  float scale;                 /* plate scale (Nt/nb)(F/fb), used with m_logit */
+} tq_ksmogn_args;
+
+int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One SVI step of the cosmos model = what `self.svi.step()` does at
+ * tapqir/models/model.py:212 (pyro SVI + TraceEnum_ELBO(max_plate_nesting=3) over
+ * cosmos.model / cosmos.guide, tapqir/models/cosmos.py:82-462, then pyro.optim.Adam,
+ * model.py:169-171), split into stages so that a data-parallel host can put ONE all-reduce
+ * of `gsum` between tq_cosmos_elbo_grads and tq_cosmos_globals_grad.
+ *
+ * Parameter storage.  All unconstrained parameters live in one flat float32 buffer
+ *   params = [ local  : (8K+2) rows x U ]   U = Nt*F*C, row order:
+ *                m_probs[k], h_loc[k], h_beta[k], w_mean[k], w_size[k], x_mean[k], y_mean[k],
+ *                size[k]  (each K rows, k-major = the reference's (K,Nt,F,Q) tensors), b_loc, b_beta
+ *            [ per-AOI: 2 rows x Nt*C ]     background_mean_loc, background_std_loc
+ *            [ global : 4 + 5Q ]            gain_loc, gain_beta, proximity_loc, proximity_size,
+ *                                           lamda_loc[Q], lamda_beta[Q], pi_mean[Q][2], pi_size[Q]
+ * with the torch `transform_to(constraint)` maps of cosmos.py:471-598 (exp / sigmoid-affine /
+ * exp+2 / softmax).  grad, exp_avg, exp_avg_sq have the same layout; `grad` receives
+ * d ELBO / d param (Adam then descends on -ELBO).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  /* dataset (device) */
+  const float* images;         /* (Nt, F, C, P, P) */
+  const float* xy;             /* (Nt, F, C, 2) */
+  const uint8_t* is_ontarget;  /* [Nt] */
+  const uint8_t* aoi_mask;     /* [Nt] or NULL */
+  const int32_t* ndx;          /* [nb] or NULL */
+  const int32_t* fdx;          /* [fb] or NULL */
+  const float* offset_samples; /* [O] (host merges duplicate samples) */
+  const float* offset_logits;  /* [O] */
+  /* parameters and optimiser state (device, flat, see above) */
+  float* params;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  /* workspace (device) */
+  float* lat;                  /* [1+4K][B]        latent draws: b, h[K], w[K], x[K], y[K] */
+  float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K] */
+  float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */
+  float* blk_part;             /* [nblk][3+3Q]     per-workgroup partial sums */
+  double* gsum;                /* [3+3Q]           cross-unit sums: d/d gain, d/d cs, ELBO, (d/d rho, a, c)[Q] */
+  void* globals;               /* TqGlobals  (tq_globals_size() bytes) */
+  void* gbase;                 /* TqGlobalBase (tq_gbase_size() bytes): base draws of the global sites */
+  double* elbo_out;            /* [1] ELBO of the step */
+  /* geometry */
+  int32_t Nt, F, C, P, K, O;
+  int32_t nb, fb;
+  int32_t n_offset;            /* global index of local AOI 0 (AOI sharding: RNG streams use global ids) */
+  int32_t draw_globals;        /* 1: draw the global base variates; 0: use the contents of gbase */
+  float scale_n;               /* Nt_global / nb_global */
+  float scale;                 /* scale_n * F / fb */
+  float global_weight;         /* weight of the global ELBO part on this rank (1 on exactly one rank for reporting) */
+  /* model constants */
+  float eps;                   /* finfo(model dtype).eps */
+  float width_min, width_max, height_std, background_mean_std, background_std_std;
+  float gain_std, lamda_rate, proximity_rate;
+  /* optimiser */
+  float lr, beta1, beta2, adam_eps;
+  float bias_correction1, bias_correction2;  /* 1 - beta^t for this step */
+  int32_t zero_grad;           /* 1: Adam clears grad after use (minibatch mode keeps grad dense-zero) */
+  /* RNG */
+  uint64_t seed;
+  uint32_t step;
+} tq_cosmos_args;
+
+int64_t tq_globals_size(void);
+int64_t tq_gbase_size(void);
+int64_t tq_cosmos_nblk(int64_t B);              /* rows of blk_part */
+int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K);
+
+/* guide draws: globals (gain, pi, lamda, proximity) + derived tables, then b, h, w, x, y per unit
+ * (cosmos.py:342-368, 408-462; torch Gamma/Beta rsample + pyro AffineBeta clamp) */
+int tq_cosmos_sample_globals(const tq_cosmos_args* a, void* stream);
+int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream);
+/* likelihood + all per-unit / per-AOI ELBO terms and gradients; fills grad (local + AOI parts) and gsum */
+int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream);
+/* global sites: chain gsum through the tables to the unconstrained global parameters; writes elbo_out */
+int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream);
+/* dense Adam over the whole flat buffer (torch.optim.Adam semantics, model.py:169-171) */
+int tq_cosmos_adam(const tq_cosmos_args* a, void* stream);
+/* all of the above back to back */
+int tq_cosmos_step(const tq_cosmos_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

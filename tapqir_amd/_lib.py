@@ -1,0 +1,116 @@
+"""
+ctypes binding of ``libtapqir_hip.so`` (C ABI declared in ``include/tapqir_hip.h``).
+
+There is no fallback: if the shared library is missing or fails to load, every entry point
+raises ``HipExtensionError``.  Build it with ``python -m tapqir_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+
+import ctypes as C
+import os
+
+from tapqir_amd.exceptions import HipExtensionError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtapqir_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class KsmognArgs(C.Structure):
+    """``tq_ksmogn_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("images", C.c_void_p), ("xy", C.c_void_p), ("ndx", C.c_void_p), ("fdx", C.c_void_p),
+        ("background", C.c_void_p), ("height", C.c_void_p), ("width", C.c_void_p),
+        ("x", C.c_void_p), ("y", C.c_void_p), ("gain", C.c_void_p),
+        ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
+        ("gout", C.c_void_p), ("m_logit", C.c_void_p), ("aoi_mask", C.c_void_p),
+        ("ll", C.c_void_p), ("g_background", C.c_void_p), ("g_height", C.c_void_p),
+        ("g_width", C.c_void_p), ("g_x", C.c_void_p), ("g_y", C.c_void_p), ("g_gain", C.c_void_p),
+        ("m_kstride", C.c_int64),
+        ("nb", C.c_int32), ("fb", C.c_int32), ("C", C.c_int32), ("F", C.c_int32),
+        ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+class CosmosArgs(C.Structure):
+    """``tq_cosmos_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("images", C.c_void_p), ("xy", C.c_void_p), ("is_ontarget", C.c_void_p), ("aoi_mask", C.c_void_p),
+        ("ndx", C.c_void_p), ("fdx", C.c_void_p), ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
+        ("params", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("lat", C.c_void_p), ("pix", C.c_void_p), ("aoi_part", C.c_void_p), ("blk_part", C.c_void_p),
+        ("gsum", C.c_void_p), ("globals", C.c_void_p), ("gbase", C.c_void_p), ("elbo_out", C.c_void_p),
+        ("Nt", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
+        ("nb", C.c_int32), ("fb", C.c_int32), ("n_offset", C.c_int32), ("draw_globals", C.c_int32),
+        ("scale_n", C.c_float), ("scale", C.c_float), ("global_weight", C.c_float),
+        ("eps", C.c_float),
+        ("width_min", C.c_float), ("width_max", C.c_float), ("height_std", C.c_float),
+        ("background_mean_std", C.c_float), ("background_std_std", C.c_float),
+        ("gain_std", C.c_float), ("lamda_rate", C.c_float), ("proximity_rate", C.c_float),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("bias_correction1", C.c_float), ("bias_correction2", C.c_float),
+        ("zero_grad", C.c_int32),
+        ("seed", C.c_uint64), ("step", C.c_uint32),
+    ]
+
+
+# every symbol include/tapqir_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "tq_version", "tq_last_error", "tq_ksmogn_log_prob",
+    "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
+    "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
+    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step",
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -m tapqir_amd.build`). "
+            "tapqir_amd has no CPU fallback for the SVI hot path."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as err:
+        raise HipExtensionError(f"failed to load {LIB_PATH}: {err}")
+    lib.tq_version.restype = C.c_int
+    lib.tq_last_error.restype = C.c_char_p
+    for name in ("tq_globals_size", "tq_gbase_size"):
+        getattr(lib, name).restype = C.c_int64
+    lib.tq_cosmos_nblk.restype = C.c_int64
+    lib.tq_cosmos_nblk.argtypes = [C.c_int64]
+    lib.tq_cosmos_param_count.restype = C.c_int64
+    lib.tq_cosmos_param_count.argtypes = [C.c_int32] * 4
+    lib.tq_ksmogn_log_prob.argtypes = [C.POINTER(KsmognArgs), C.c_void_p]
+    lib.tq_ksmogn_log_prob.restype = C.c_int
+    for name in ("tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
+                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step"):
+        fn = getattr(lib, name)
+        fn.argtypes = [C.POINTER(CosmosArgs), C.c_void_p]
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tq_last_error().decode()
+        raise HipExtensionError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Raw address of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()

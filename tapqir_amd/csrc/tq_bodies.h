@@ -1,0 +1,197 @@
+// tq_bodies.h -- per-work-item bodies of the cosmos step kernels (host+device inline).
+// The __global__ wrappers in tq_cosmos.hip call these with the work-item index; the CPU test
+// harness (tests/hostcheck) calls the same bodies in plain loops on host memory.
+#pragma once
+#include "../../include/tapqir_hip.h"
+#include "tq_globals.h"
+#include "tq_site.h"
+
+struct TqUnitIdx {
+  int n, f, c;
+  int64_t u;  // dataset unit index (n*F + f)*C + c
+};
+
+TQ_HD TqUnitIdx tq_decode_unit(const tq_cosmos_args& a, int64_t i) {
+  TqUnitIdx r;
+  r.c = (int)(i % a.C);
+  const int64_t ab = i / a.C;
+  const int bi = (int)(ab % a.fb), ai = (int)(ab / a.fb);
+  r.n = a.ndx ? a.ndx[ai] : ai;
+  r.f = a.fdx ? a.fdx[bi] : bi;
+  r.u = ((int64_t)r.n * a.F + r.f) * a.C + r.c;
+  return r;
+}
+
+TQ_HD int64_t tq_num_units(const tq_cosmos_args& a) { return (int64_t)a.Nt * a.F * a.C; }
+TQ_HD int64_t tq_batch_units(const tq_cosmos_args& a) { return (int64_t)a.nb * a.fb * a.C; }
+TQ_HD int64_t tq_aoi_base(const tq_cosmos_args& a) { return (int64_t)TQ_NLOCAL(a.K) * tq_num_units(a); }
+TQ_HD int64_t tq_global_base(const tq_cosmos_args& a) { return tq_aoi_base(a) + 2 * (int64_t)a.Nt * a.C; }
+
+TQ_HD TqGlobalConsts tq_global_consts(const tq_cosmos_args& a) {
+  TqGlobalConsts c;
+  c.K = a.K; c.P = a.P; c.Q = a.C;
+  c.eps = a.eps;
+  c.gain_std = a.gain_std; c.lamda_rate = a.lamda_rate; c.proximity_rate = a.proximity_rate;
+  return c;
+}
+
+// ---- global sites: draw + tables (one work item) ------------------------------------------------------
+TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a) {
+  const TqGlobalConsts C = tq_global_consts(a);
+  TqGlobalParams p;
+  tq_globals_constrain(a.params + tq_global_base(a), C, &p);
+  TqGlobalBase* gb = (TqGlobalBase*)a.gbase;
+  if (a.draw_globals) tq_globals_draw(p, C, a.seed, a.step, gb);
+  tq_globals_tables(p, *gb, C, (TqGlobals*)a.globals);
+}
+
+// ---- local guide draws: work item t = site * B + i, site in [0, 1+4K): b, h[k], w[k], x[k], y[k] ---------
+TQ_HD void tq_body_sample_local(const tq_cosmos_args& a, int64_t t) {
+  const int K = a.K;
+  const int64_t B = tq_batch_units(a), U = tq_num_units(a);
+  const int site = (int)(t / B);
+  const int64_t i = t % B;
+  const TqUnitIdx ix = tq_decode_unit(a, i);
+  const float* P = a.params;
+  const uint64_t elem = ((uint64_t)(ix.n + a.n_offset) * a.F + ix.f) * a.C + ix.c;
+  TqPhilox s;
+  tq_philox_init(&s, a.seed, a.step, (uint32_t)site, elem);
+  const float tiny = 1.17549435e-38f;
+  float val;
+  if (site == 0 || site <= K) {  // Gamma(loc*beta, beta): background or height
+    const int rl = site == 0 ? TQ_ROW_BLOC(K) : TQ_ROW(TQ_P_HLOC, site - 1, K);
+    const int rb = site == 0 ? TQ_ROW_BBETA(K) : TQ_ROW(TQ_P_HBETA, site - 1, K);
+    const float ul = P[rl * U + ix.u], ub = P[rb * U + ix.u];
+    const float alpha = expf(ul + ub), beta = expf(ub);
+    val = fmaxf(tq_sample_std_gamma(&s, alpha) / beta, tiny);
+  } else {  // AffineBeta
+    const int j = site - 1 - K;
+    const int kind = j / K, k = j % K;  // 0: width, 1: x, 2: y
+    float lo, hi, um, us;
+    if (kind == 0) {
+      lo = a.width_min; hi = a.width_max;
+      um = P[TQ_ROW(TQ_P_WMEAN, k, K) * U + ix.u];
+      us = P[TQ_ROW(TQ_P_WSIZE, k, K) * U + ix.u];
+    } else {
+      const float H = 0.5f * (a.P + 1);
+      lo = -H; hi = H;
+      um = P[TQ_ROW(kind == 1 ? TQ_P_XMEAN : TQ_P_YMEAN, k, K) * U + ix.u];
+      us = P[TQ_ROW(TQ_P_SIZE, k, K) * U + ix.u];
+    }
+    const float sc = hi - lo;
+    const float mean = (lo + a.eps) + (sc - 2.0f * a.eps) * tq_sigmoid(um);
+    const float size = 2.0f + expf(us);
+    const float c1 = size * (mean - lo) / sc, c0 = size * (hi - mean) / sc;
+    const float g1 = tq_sample_std_gamma(&s, c1), g0 = tq_sample_std_gamma(&s, c0);
+    float tt = g1 / (g1 + g0);
+    tt = fminf(fmaxf(tt, tiny), 1.0f - 5.96046448e-08f);  // torch._sample_dirichlet clamp
+    val = fminf(fmaxf(lo + sc * tt, lo + a.eps * sc), hi - a.eps * sc);  // pyro AffineBeta.rsample clamp
+  }
+  a.lat[(int64_t)site * B + i] = val;
+}
+
+// ---- per-unit ELBO terms and gradients --------------------------------------------------------------------
+// part[] receives this unit's contribution to the cross-unit sums (layout TQ_GS_*).
+template <int K>
+TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
+  constexpr int M = 1 << K;
+  constexpr int NL = TQ_NLOCAL(K);
+  const int64_t B = tq_batch_units(a), U = tq_num_units(a);
+  const TqUnitIdx ix = tq_decode_unit(a, i);
+  const TqGlobals& G = *(const TqGlobals*)a.globals;
+  TqSiteConsts C;
+  C.H = 0.5f * (a.P + 1);
+  C.eps = a.eps;
+  C.w_lo = a.width_min; C.w_hi = a.width_max;
+  C.height_std = a.height_std;
+  C.bg_mean_std = a.background_mean_std; C.bg_std_std = a.background_std_std;
+
+  TqUnitIn<K> in;
+#pragma unroll
+  for (int r = 0; r < NL; ++r) in.u[r] = a.params[(int64_t)r * U + ix.u];
+  const int64_t ab = tq_aoi_base(a);
+  const int64_t nc = (int64_t)ix.n * a.C + ix.c;
+  in.u_bml = a.params[ab + nc];
+  in.u_bsl = a.params[ab + (int64_t)a.Nt * a.C + nc];
+  in.b = a.lat[i];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    in.h[k] = a.lat[(int64_t)(1 + k) * B + i];
+    in.w[k] = a.lat[(int64_t)(1 + K + k) * B + i];
+    in.x[k] = a.lat[(int64_t)(1 + 2 * K + k) * B + i];
+    in.y[k] = a.lat[(int64_t)(1 + 3 * K + k) * B + i];
+  }
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) in.ll[mi] = a.pix[(int64_t)mi * B + i];
+  in.gb = a.pix[(int64_t)M * B + i];
+  const float g_gain = a.pix[(int64_t)(M + 1) * B + i];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    in.gh[k] = a.pix[(int64_t)(M + 2 + k) * B + i];
+    in.gw[k] = a.pix[(int64_t)(M + 2 + K + k) * B + i];
+    in.gx[k] = a.pix[(int64_t)(M + 2 + 2 * K + k) * B + i];
+    in.gy[k] = a.pix[(int64_t)(M + 2 + 3 * K + k) * B + i];
+  }
+  const bool masked = a.aoi_mask && !a.aoi_mask[ix.n];
+  in.wu = masked ? 0.0f : a.scale;
+  in.on = a.is_ontarget[ix.n] ? 1 : 0;
+  in.q = ix.c;
+
+  TqUnitOut<K> out;
+  tq_cosmos_unit<K>(in, G, C, &out);
+
+#pragma unroll
+  for (int r = 0; r < NL; ++r) a.grad[(int64_t)r * U + ix.u] = masked ? 0.0f : out.g[r];
+  a.aoi_part[i] = masked ? 0.0f : out.g_bml;
+  a.aoi_part[B + i] = masked ? 0.0f : out.g_bsl;
+
+  const int nq = 3 + 3 * a.C;
+  for (int j = 0; j < nq; ++j) part[j] = 0.0f;
+  if (!masked) {
+    part[TQ_GS_GAIN] = g_gain;
+    part[TQ_GS_CS] = out.d_cs;
+    part[TQ_GS_ELBO] = out.elbo;
+    part[TQ_GS_Q0 + 3 * ix.c + 0] = out.d_rho;
+    part[TQ_GS_Q0 + 3 * ix.c + 1] = out.d_a;
+    part[TQ_GS_Q0 + 3 * ix.c + 2] = out.d_c;
+  }
+}
+
+// ---- per-AOI: finish d/d(background_mean_loc, background_std_loc) given the frame sums --------------------
+TQ_HD void tq_body_aoi_finish(const tq_cosmos_args& a, int ai, int c, float sum_bml, float sum_bsl, float* elbo) {
+  const int n = a.ndx ? a.ndx[ai] : ai;
+  const bool masked = a.aoi_mask && !a.aoi_mask[n];
+  TqSiteConsts C;
+  C.bg_mean_std = a.background_mean_std; C.bg_std_std = a.background_std_std;
+  const int64_t ab = tq_aoi_base(a), nc = (int64_t)n * a.C + c, NC = (int64_t)a.Nt * a.C;
+  float e = 0.0f, g1 = 0.0f, g2 = 0.0f;
+  if (!masked) tq_cosmos_aoi(a.params[ab + nc], a.params[ab + NC + nc], a.scale_n, C, &e, &g1, &g2);
+  a.grad[ab + nc] = masked ? 0.0f : (sum_bml + g1);
+  a.grad[ab + NC + nc] = masked ? 0.0f : (sum_bsl + g2);
+  *elbo = e;
+}
+
+// ---- global sites: gradient (one work item) ---------------------------------------------------------------
+TQ_HD void tq_body_globals_grad(const tq_cosmos_args& a) {
+  const TqGlobalConsts C = tq_global_consts(a);
+  const float* u = a.params + tq_global_base(a);
+  TqGlobalParams p;
+  tq_globals_constrain(u, C, &p);
+  double g_u[TQ_NGLOBAL(TQ_MAXQ)];
+  const double eg = tq_globals_grad(u, p, *(const TqGlobalBase*)a.gbase, *(const TqGlobals*)a.globals, C, a.gsum, g_u);
+  float* g = a.grad + tq_global_base(a);
+  for (int j = 0; j < TQ_NGLOBAL(a.C); ++j) g[j] = (float)g_u[j];
+  a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
+}
+
+// ---- Adam on one element (torch.optim.Adam, no amsgrad / weight decay; minimises -ELBO) ------------------
+TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
+  const float g = -a.grad[j];
+  const float m = a.beta1 * a.exp_avg[j] + (1.0f - a.beta1) * g;
+  const float v = a.beta2 * a.exp_avg_sq[j] + (1.0f - a.beta2) * g * g;
+  a.exp_avg[j] = m;
+  a.exp_avg_sq[j] = v;
+  const float denom = sqrtf(v) / sqrtf(a.bias_correction2) + a.adam_eps;
+  a.params[j] -= (a.lr / a.bias_correction1) * (m / denom);
+  if (a.zero_grad) a.grad[j] = 0.0f;
+}

@@ -1,0 +1,248 @@
+// tq_cosmos.hip -- kernels of one cosmos SVI step around the pixel kernel of tq_ksmogn.hip
+// (guide sampling, per-unit ELBO terms + gradients, per-AOI terms, cross-unit sums, global
+// sites, dense Adam).  Replaces what pyro's SVI/TraceEnum_ELBO/optim.Adam execute for
+// tapqir/models/model.py:212 -- see include/tapqir_hip.h.
+//
+// Launch shapes: everything except the pixel kernel is one lane per work item, SoA so that
+// consecutive lanes touch consecutive addresses (the flat parameter buffer is [row][unit]).
+// Cross-unit sums are deterministic: wave64 __shfl_down -> LDS -> one row per workgroup ->
+// a single-workgroup fp64 finish; no float atomics.
+#include <hip/hip_runtime.h>
+
+#include "tq_bodies.h"
+
+void tq_set_error(const char* msg);
+
+#define TQ_UNIT_BLOCK 256
+#define TQ_MAX_NGSUM (3 + 3 * TQ_MAXQ)
+
+__device__ __forceinline__ float tq_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ---- sampling ------------------------------------------------------------------------------------------
+__global__ void tq_sample_globals_kernel(const tq_cosmos_args a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) tq_body_sample_globals(a);
+}
+
+__global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < total) tq_body_sample_local(a, t);
+}
+
+// ---- per-unit terms ------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_kernel(const tq_cosmos_args a, const int64_t B) {
+  __shared__ float s_part[TQ_UNIT_BLOCK / 64][TQ_MAX_NGSUM];
+  const int64_t i = (int64_t)blockIdx.x * TQ_UNIT_BLOCK + threadIdx.x;
+  const int nq = 3 + 3 * a.C;
+  float part[TQ_MAX_NGSUM];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
+  if (i < B) tq_body_unit<K>(a, i, part);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const float s = tq_wave_sum(part[j]);
+      if (lane == 0) s_part[wave][j] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nq) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < TQ_UNIT_BLOCK / 64; ++w) s += s_part[w][threadIdx.x];
+    a.blk_part[(int64_t)blockIdx.x * nq + threadIdx.x] = s;
+  }
+}
+
+// ---- per-AOI terms: one wave per (a, c), lanes stride the frames --------------------------------------
+__global__ __launch_bounds__(256) void tq_aoi_kernel(const tq_cosmos_args a, const int64_t B) {
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int nac = a.nb * a.C;
+  if (wave >= nac) return;
+  const int ai = wave / a.C, c = wave % a.C;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int b = lane; b < a.fb; b += 64) {
+    const int64_t i = ((int64_t)ai * a.fb + b) * a.C + c;
+    s1 += a.aoi_part[i];
+    s2 += a.aoi_part[B + i];
+  }
+  s1 = tq_wave_sum(s1);
+  s2 = tq_wave_sum(s2);
+  if (lane == 0) {
+    float e;
+    tq_body_aoi_finish(a, ai, c, s1, s2, &e);
+    a.aoi_part[2 * B + wave] = e;  // per-AOI prior part of the ELBO (row 2 is scratch, nb*C <= B)
+  }
+}
+
+// ---- finish the cross-unit sums in fp64 (single workgroup) -----------------------------------------------
+__global__ __launch_bounds__(256) void tq_reduce_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
+  __shared__ double s_red[256];
+  const int nq = 3 + 3 * a.C;
+  for (int j = 0; j < nq; ++j) {
+    double s = 0.0;
+    for (int64_t r = threadIdx.x; r < nblk; r += 256) s += (double)a.blk_part[r * nq + j];
+    if (j == TQ_GS_ELBO) {
+      const int nac = a.nb * a.C;
+      for (int r = threadIdx.x; r < nac; r += 256) s += (double)a.aoi_part[2 * B + r];
+    }
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.gsum[j] = s_red[0];
+    __syncthreads();
+  }
+}
+
+__global__ void tq_globals_grad_kernel(const tq_cosmos_args a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) tq_body_globals_grad(a);
+}
+
+__global__ __launch_bounds__(256) void tq_adam_kernel(const tq_cosmos_args a, const int64_t total) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) tq_body_adam(a, j);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    tq_set_error(buf);
+    return TQ_ERR_LAUNCH;
+  }
+  return TQ_OK;
+}
+
+static int check_args(const tq_cosmos_args* a, const char* who) {
+  if (!a || !a->params || !a->globals || !a->gbase) {
+    tq_set_error("tq_cosmos_*: NULL args/params/globals/gbase");
+    return TQ_ERR_ARG;
+  }
+  if (a->K < 1 || a->K > TQ_MAX_K || a->P < 2 || a->P > TQ_MAX_P || a->C < 1 || a->C > TQ_MAXQ || a->nb < 1 ||
+      a->fb < 1 || a->nb > a->Nt || a->fb > a->F || a->O < 1) {
+    tq_set_error("tq_cosmos_*: unsupported K/P/C or inconsistent batch geometry");
+    return TQ_ERR_ARG;
+  }
+  (void)who;
+  return TQ_OK;
+}
+
+extern "C" int64_t tq_globals_size(void) { return (int64_t)sizeof(TqGlobals); }
+extern "C" int64_t tq_gbase_size(void) { return (int64_t)sizeof(TqGlobalBase); }
+extern "C" int64_t tq_cosmos_nblk(int64_t B) { return (B + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK; }
+extern "C" int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K) {
+  return (int64_t)TQ_NLOCAL(K) * Nt * F * C + 2 * (int64_t)Nt * C + TQ_NGLOBAL(C);
+}
+
+extern "C" int tq_cosmos_sample_globals(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "sample_globals")) return rc;
+  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+  return check_launch("tq_sample_globals_kernel");
+}
+
+extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "sample_locals")) return rc;
+  if (!a->lat) {
+    tq_set_error("tq_cosmos_sample_locals: lat is NULL");
+    return TQ_ERR_ARG;
+  }
+  const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
+  hipLaunchKernelGGL(tq_sample_locals_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, *a, total);
+  return check_launch("tq_sample_locals_kernel");
+}
+
+extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "elbo_grads")) return rc;
+  if (!a->images || !a->xy || !a->is_ontarget || !a->offset_samples || !a->offset_logits || !a->grad || !a->lat ||
+      !a->pix || !a->aoi_part || !a->blk_part || !a->gsum) {
+    tq_set_error("tq_cosmos_elbo_grads: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int K = a->K, M = 1 << K;
+  const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
+  // 1. pixel kernel: fused render + log-likelihood + pathwise gradients, Dice weights from m_probs
+  tq_ksmogn_args k = {};
+  k.images = a->images; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
+  k.background = a->lat;
+  k.height = a->lat + (int64_t)1 * B;
+  k.width = a->lat + (int64_t)(1 + K) * B;
+  k.x = a->lat + (int64_t)(1 + 2 * K) * B;
+  k.y = a->lat + (int64_t)(1 + 3 * K) * B;
+  k.gain = &((const TqGlobals*)a->globals)->gain;
+  k.offset_samples = a->offset_samples; k.offset_logits = a->offset_logits;
+  k.gout = nullptr;
+  k.m_logit = a->params;  // rows TQ_ROW(TQ_P_MPROBS, k, K) = k
+  k.m_kstride = U;
+  k.aoi_mask = a->aoi_mask;
+  k.ll = a->pix;
+  k.g_background = a->pix + (int64_t)M * B;
+  k.g_gain = a->pix + (int64_t)(M + 1) * B;
+  k.g_height = a->pix + (int64_t)(M + 2) * B;
+  k.g_width = a->pix + (int64_t)(M + 2 + K) * B;
+  k.g_x = a->pix + (int64_t)(M + 2 + 2 * K) * B;
+  k.g_y = a->pix + (int64_t)(M + 2 + 3 * K) * B;
+  k.nb = a->nb; k.fb = a->fb; k.C = a->C; k.F = a->F; k.P = a->P; k.K = K; k.O = a->O;
+  k.scale = a->scale;
+  if (int rc = tq_ksmogn_log_prob(&k, stream)) return rc;
+  // 2. per-unit sites
+  const int64_t nblk = tq_cosmos_nblk(B);
+  const dim3 grid((unsigned)nblk), block(TQ_UNIT_BLOCK);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((tq_unit_kernel<1>), grid, block, 0, st, *a, B); break;
+    case 2: hipLaunchKernelGGL((tq_unit_kernel<2>), grid, block, 0, st, *a, B); break;
+    case 3: hipLaunchKernelGGL((tq_unit_kernel<3>), grid, block, 0, st, *a, B); break;
+    default: hipLaunchKernelGGL((tq_unit_kernel<4>), grid, block, 0, st, *a, B); break;
+  }
+  if (int rc = check_launch("tq_unit_kernel")) return rc;
+  // 3. per-AOI sites
+  const int64_t nwaves = (int64_t)a->nb * a->C;
+  hipLaunchKernelGGL(tq_aoi_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, st, *a, B);
+  if (int rc = check_launch("tq_aoi_kernel")) return rc;
+  // 4. cross-unit sums
+  hipLaunchKernelGGL(tq_reduce_kernel, dim3(1), dim3(256), 0, st, *a, nblk, B);
+  return check_launch("tq_reduce_kernel");
+}
+
+extern "C" int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "globals_grad")) return rc;
+  if (!a->grad || !a->gsum || !a->elbo_out) {
+    tq_set_error("tq_cosmos_globals_grad: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+  return check_launch("tq_globals_grad_kernel");
+}
+
+extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "adam")) return rc;
+  if (!a->grad || !a->exp_avg || !a->exp_avg_sq) {
+    tq_set_error("tq_cosmos_adam: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  const int64_t total = tq_cosmos_param_count(a->Nt, a->F, a->C, a->K);
+  int64_t nblk = (total + 255) / 256;
+  if (nblk > 256 * 16) nblk = 256 * 16;  // grid-stride: 16 workgroups per CU
+  hipLaunchKernelGGL(tq_adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, *a, total);
+  return check_launch("tq_adam_kernel");
+}
+
+extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {
+  if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
+  if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
+  if (int rc = tq_cosmos_elbo_grads(a, stream)) return rc;
+  if (int rc = tq_cosmos_globals_grad(a, stream)) return rc;
+  return tq_cosmos_adam(a, stream);
+}

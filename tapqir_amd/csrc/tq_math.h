@@ -1,0 +1,399 @@
+// tq_math.h -- scalar building blocks shared by every kernel of the cosmos hot path.
+//
+// Everything here is a small inline function on scalars so that (a) the HIP kernels
+// (tq_*.hip, compiled for gfx950) and (b) the host-side checker used by the CPU test
+// suite (tests/hostcheck, compiled with g++) run the SAME arithmetic.  The checker is
+// test infrastructure only; the product never falls back to it.
+//
+// Contents
+//   * Philox4x32-10 counter RNG, uniform / normal draws
+//   * Marsaglia-Tsang standard-Gamma sampler (the algorithm torch.distributions.Gamma
+//     uses: aten/src/ATen/native/Distributions.h `sample_gamma`)
+//   * lgamma / digamma through the Binet function S(a) = lgamma(a) - [(a-1/2)ln a - a + ln sqrt(2 pi)]
+//   * implicit reparameterisation gradients of Gamma and Beta/Dirichlet draws
+//     (Figurnov et al. 2018; Jankowiak & Obermeyer 2018).  The piecewise scheme and the
+//     fitted rational coefficients are those published in PyTorch (BSD-3,
+//     ATen/native/Distributions.h: standard_gamma_grad_one, dirichlet_grad_one) because
+//     the reference's gradients are *defined* by them (pyro rsample -> torch.autograd).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TQ_HD __host__ __device__ __forceinline__
+#else
+#define TQ_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// v_log_f32 / v_exp_f32 / v_rcp_f32: one quarter-rate instruction each on CDNA4.
+#define TQ_FLOG(x) __logf(x)
+#define TQ_FEXP(x) __expf(x)
+#define TQ_FRCP(x) __frcp_rn(x)
+#else
+#define TQ_FLOG(x) logf(x)
+#define TQ_FEXP(x) expf(x)
+#define TQ_FRCP(x) (1.0f / (x))
+#endif
+
+#define TQ_LN_SQRT_2PI 0.91893853320467274178f
+#define TQ_LN2 0.69314718055994530942f
+#define TQ_PI 3.14159265358979323846f
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  key = (seed_lo, seed_hi); counter = 128 bit.
+// ------------------------------------------------------------------------------------------
+struct TqPhilox {
+  uint32_t c[4];
+  uint32_t k[2];
+  uint32_t out[4];
+  int have;  // unread words in out
+};
+
+TQ_HD void tq_philox_round(uint32_t* c, const uint32_t* k) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+TQ_HD void tq_philox_block(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+  uint32_t k[2] = {key[0], key[1]};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    tq_philox_round(c, k);
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// stream = (seed, step, site id, element id): every latent scalar owns a counter sequence,
+// so results do not depend on the launch geometry or on how AOIs are sharded over GPUs.
+TQ_HD void tq_philox_init(TqPhilox* s, uint64_t seed, uint32_t step, uint32_t site, uint64_t elem) {
+  s->k[0] = (uint32_t)seed;
+  s->k[1] = (uint32_t)(seed >> 32);
+  s->c[0] = 0;  // block counter within the stream
+  s->c[1] = (uint32_t)elem;
+  s->c[2] = (uint32_t)(elem >> 32) ^ (site << 20);
+  s->c[3] = step;
+  s->have = 0;
+}
+
+TQ_HD uint32_t tq_philox_next(TqPhilox* s) {
+  if (s->have == 0) {
+    tq_philox_block(s->c, s->k, s->out);
+    s->c[0] += 1;
+    s->have = 4;
+  }
+  s->have -= 1;
+  return s->out[3 - s->have];
+}
+
+// uniform on the open interval (0, 1): 24 random bits, centred
+TQ_HD float tq_uniform(TqPhilox* s) {
+  return (float)(tq_philox_next(s) >> 8) * 5.9604644775390625e-08f + 2.98023223876953125e-08f;
+}
+
+TQ_HD float tq_normal(TqPhilox* s) {  // Box-Muller, one value per call (the sine branch is dropped)
+  const float u1 = tq_uniform(s);
+  const float u2 = tq_uniform(s);
+  return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * TQ_PI * u2);
+}
+
+// Standard Gamma(alpha, 1) draw; Marsaglia & Tsang (2000) with the alpha < 1 boost.
+TQ_HD float tq_sample_std_gamma(TqPhilox* s, float alpha) {
+  float scale = 1.0f;
+  if (alpha < 1.0f) {
+    if (alpha == 0.0f) return 0.0f;
+    scale = powf(1.0f - tq_uniform(s), 1.0f / alpha);
+    alpha += 1.0f;
+  }
+  const float d = alpha - 1.0f / 3.0f;
+  const float c = 1.0f / sqrtf(9.0f * d);
+  for (int it = 0; it < 64; ++it) {  // acceptance > 95 %; the bound only guards against a stuck wave
+    float x, y;
+    int guard = 0;
+    do {
+      x = tq_normal(s);
+      y = 1.0f + c * x;
+    } while (y <= 0.0f && ++guard < 64);
+    const float v = y * y * y;
+    const float u = 1.0f - tq_uniform(s);
+    const float xx = x * x;
+    if (u < 1.0f - 0.0331f * xx * xx) return scale * d * v;
+    if (logf(u) < 0.5f * xx + d * (1.0f - v + logf(v))) return scale * d * v;
+  }
+  return scale * d;  // practically unreachable (p < 1e-80)
+}
+
+// ------------------------------------------------------------------------------------------
+// lgamma / digamma via the Binet function.
+//   lgamma(a)  = (a - 1/2) ln a - a + ln sqrt(2 pi) + S(a)
+//   digamma(a) = ln a - 1/(2a) + S'(a)
+//   S(a)  =  1/(12a) - 1/(360a^3) + 1/(1260a^5) - 1/(1680a^7)
+//   S'(a) = -1/(12a^2) + 1/(120a^4) - 1/(252a^6) + 1/(240a^8)
+// Series for a >= 8 (truncation < 3e-10); below that, shift up by 8 with the recurrences
+// lgamma(a) = lgamma(a+8) - ln prod_{i<8}(a+i), digamma(a) = digamma(a+8) - sum_{i<8} 1/(a+i).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+TQ_HD void tq_binet_series(T a, T ra, T* S, T* dS) {
+  const T r2 = ra * ra;
+  *S = ra * (T(1.0 / 12.0) + r2 * (T(-1.0 / 360.0) + r2 * (T(1.0 / 1260.0) + r2 * T(-1.0 / 1680.0))));
+  *dS = r2 * (T(-1.0 / 12.0) + r2 * (T(1.0 / 120.0) + r2 * (T(-1.0 / 252.0) + r2 * T(1.0 / 240.0))));
+}
+
+// Binet function and its derivative for any a > 0, given ln a and 1/a.
+TQ_HD void tq_binet(float a, float lna, float ra, float* S, float* dS) {
+  if (a >= 8.0f) {
+    tq_binet_series<float>(a, ra, S, dS);
+    return;
+  }
+  // slow path (rare on the pixel path: needs background/gain < 8)
+  float prod = 1.0f, rsum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float ai = a + (float)i;
+    prod *= ai;
+    rsum += 1.0f / ai;
+  }
+  const float b = a + 8.0f;
+  const float lnb = logf(b), rb = 1.0f / b;
+  float Sb, dSb;
+  tq_binet_series<float>(b, rb, &Sb, &dSb);
+  // lgamma(a) = (b-1/2)ln b - b + c + Sb - ln prod  and  S(a) = lgamma(a) - (a-1/2)ln a + a - c
+  *S = (b - 0.5f) * lnb - 8.0f + Sb - logf(prod) - (a - 0.5f) * lna;
+  // digamma(a) = ln b - 1/(2b) + dSb - rsum ; S'(a) = digamma(a) - ln a + 1/(2a)
+  *dS = (lnb - lna) - 0.5f * rb + dSb - rsum + 0.5f * ra;
+}
+
+TQ_HD float tq_lgamma(float a) {
+  const float lna = logf(a), ra = 1.0f / a;
+  float S, dS;
+  tq_binet(a, lna, ra, &S, &dS);
+  return (a - 0.5f) * lna - a + TQ_LN_SQRT_2PI + S;
+}
+
+TQ_HD float tq_digamma(float a) {
+  const float lna = logf(a), ra = 1.0f / a;
+  float S, dS;
+  tq_binet(a, lna, ra, &S, &dS);
+  return lna - 0.5f * ra + dS;
+}
+
+TQ_HD void tq_lgamma_digamma(float a, float* lg, float* dg) {
+  const float lna = logf(a), ra = 1.0f / a;
+  float S, dS;
+  tq_binet(a, lna, ra, &S, &dS);
+  *lg = (a - 0.5f) * lna - a + TQ_LN_SQRT_2PI + S;
+  *dg = lna - 0.5f * ra + dS;
+}
+
+// double-precision versions (host-side globals math and the mid-range Beta gradient)
+TQ_HD void tq_lgamma_digamma_d(double a, double* lg, double* dg) {
+  double shift_l = 0.0, shift_d = 0.0;
+  while (a < 12.0) {
+    shift_l += log(a);
+    shift_d += 1.0 / a;
+    a += 1.0;
+  }
+  const double ra = 1.0 / a, r2 = ra * ra, lna = log(a);
+  const double S = ra * (1.0 / 12.0 + r2 * (-1.0 / 360.0 + r2 * (1.0 / 1260.0 + r2 * (-1.0 / 1680.0 + r2 * (1.0 / 1188.0)))));
+  const double dS = r2 * (-1.0 / 12.0 + r2 * (1.0 / 120.0 + r2 * (-1.0 / 252.0 + r2 * (1.0 / 240.0 + r2 * (-1.0 / 132.0)))));
+  *lg = (a - 0.5) * lna - a + 0.91893853320467274178 + S - shift_l;
+  *dg = lna - 0.5 * ra + dS - shift_d;
+}
+
+// ------------------------------------------------------------------------------------------
+// numerically safe logistic helpers (unconstrained -> constrained transforms)
+// ------------------------------------------------------------------------------------------
+TQ_HD float tq_softplus(float u) {  // ln(1 + e^u)
+  return u > 0.0f ? u + log1pf(expf(-u)) : log1pf(expf(u));
+}
+TQ_HD float tq_sigmoid(float u) {
+  if (u >= 0.0f) return 1.0f / (1.0f + expf(-u));
+  const float e = expf(u);
+  return e / (1.0f + e);
+}
+
+// ------------------------------------------------------------------------------------------
+// Implicit reparameterisation gradient  d g / d alpha  of g ~ Gamma(alpha, 1):
+//   -(d/dalpha CDF(g; alpha)) / pdf(g; alpha)
+// ------------------------------------------------------------------------------------------
+TQ_HD float tq_std_gamma_grad(float alpha_, float x_) {
+  // evaluated in double: the saddle-point branch cancels badly in float and this runs
+  // once per latent scalar, not per pixel
+  const double x = x_, alpha = alpha_;
+  if (x < 0.8) {  // Taylor series of the lower incomplete gamma function in x
+    double numer = 1.0, denom = alpha;
+    double series1 = numer / denom, series2 = numer / (denom * denom);
+    for (int i = 1; i <= 5; ++i) {
+      numer *= -x / (double)i;
+      denom += 1.0;
+      series1 += numer / denom;
+      series2 += numer / (denom * denom);
+    }
+    const double pow_x_alpha = pow(x, alpha);
+    const double gamma_pdf = pow(x, alpha - 1.0) * exp(-x);
+    const double gamma_cdf = pow_x_alpha * series1;
+    double lg, dg;
+    tq_lgamma_digamma_d(alpha, &lg, &dg);
+    const double gamma_cdf_alpha = (log(x) - dg) * gamma_cdf - pow_x_alpha * series2;
+    const double result = -gamma_cdf_alpha / gamma_pdf;
+    return (result != result) ? 0.0f : (float)result;
+  }
+  if (alpha > 8.0) {  // Rice saddle-point expansion
+    if (0.9 * alpha <= x && x <= 1.1 * alpha) {
+      const double numer_1 = 1.0 + 24.0 * alpha * (1.0 + 12.0 * alpha);
+      const double numer_2 = 1440.0 * (alpha * alpha) + 6.0 * x * (53.0 - 120.0 * x) - 65.0 * x * x / alpha +
+                             alpha * (107.0 + 3600.0 * x);
+      const double denom = 1244160.0 * (alpha * alpha) * (alpha * alpha);
+      return (float)(numer_1 * numer_2 / denom);
+    }
+    const double denom = sqrt(8.0 * alpha);
+    const double term2 = denom / (alpha - x);
+    const double term3 = pow(x - alpha - alpha * log(x / alpha), -1.5);
+    const double term23 = (x < alpha) ? term2 - term3 : term2 + term3;
+    const double term1 = log(x / alpha) * term23 - sqrt(2.0 / alpha) * (alpha + x) / ((alpha - x) * (alpha - x));
+    const double stirling = 1.0 + 1.0 / (12.0 * alpha) * (1.0 + 1.0 / (24.0 * alpha));
+    const double numer = x * term1;
+    return (float)(-stirling * numer / denom);
+  }
+  // bivariate rational approximation in (ln(x/alpha), ln alpha); coefficients: PyTorch (BSD-3)
+  const double u = log(x / alpha);
+  const double v = log(alpha);
+  const double coef_uv[3][8] = {
+      {0.16009398, -0.094634809, 0.025146376, -0.0030648343, 1, 0.32668115, 0.10406089, 0.0014179084},
+      {0.53487893, 0.1298071, 0.065735949, -0.0015649758, 0.16639465, 0.020070113, -0.0035938915, -0.00058392623},
+      {0.040121004, -0.0065914022, -0.0026286047, -0.0013441777, 0.017050642, -0.0021309326, 0.00085092367,
+       -1.5247877e-07},
+  };
+  double coef_v[8];
+  for (int i = 0; i < 8; ++i) coef_v[i] = coef_uv[0][i] + u * (coef_uv[1][i] + u * coef_uv[2][i]);
+  const double p = coef_v[0] + v * (coef_v[1] + v * (coef_v[2] + v * coef_v[3]));
+  const double q = coef_v[4] + v * (coef_v[5] + v * (coef_v[6] + v * coef_v[7]));
+  return (float)exp(p / q);
+}
+
+// ------------------------------------------------------------------------------------------
+// Scaled implicit gradient of x ~ Beta(alpha, total - alpha):
+//   -(d/dalpha CDF(x; alpha, beta)) / pdf(x; alpha, beta) / (1 - x)
+// (the quantity torch._dirichlet_grad returns; Dirichlet/Beta rsample backward is built on it)
+// ------------------------------------------------------------------------------------------
+TQ_HD double tq_digamma_d(double a) {
+  double lg, dg;
+  tq_lgamma_digamma_d(a, &lg, &dg);
+  return dg;
+}
+
+TQ_HD double tq_beta_grad_alpha_small(double x, double alpha, double beta) {
+  const double factor = tq_digamma_d(alpha) - tq_digamma_d(alpha + beta) - log(x);
+  double numer = 1.0;
+  double series = numer / alpha * (factor + 1.0 / alpha);
+  for (int i = 1; i <= 10; ++i) {
+    const double ci = (double)i;
+    numer *= (ci - beta) * x / ci;
+    const double denom = alpha + ci;
+    series += numer / denom * (factor + 1.0 / denom);
+  }
+  const double result = x * pow(1.0 - x, -beta) * series;
+  return (result != result) ? 0.0 : result;
+}
+
+TQ_HD double tq_beta_grad_beta_small(double x, double alpha, double beta) {
+  const double factor = tq_digamma_d(alpha + beta) - tq_digamma_d(beta);
+  double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor / alpha;
+  for (int i = 1; i <= 8; ++i) {
+    const double ci = (double)i;
+    numer *= -x / ci;
+    dbetas = dbetas * (beta - ci) + betas;
+    betas = betas * (beta - ci);
+    series += numer / (alpha + ci) * (dbetas + factor * betas);
+  }
+  const double result = -pow(1.0 - x, 1.0 - beta) * series;
+  return (result != result) ? 0.0 : result;
+}
+
+TQ_HD double tq_beta_grad_alpha_mid(double x, double alpha, double beta) {
+  const double total = alpha + beta;
+  const double mean = alpha / total;
+  const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+  if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) {  // removable singularity at x = mean
+    const double b2 = beta * beta;
+    const double poly =
+        47.0 * x * b2 * b2 +
+        alpha * ((43.0 + 20.0 * (16.0 + 27.0 * beta) * x) * b2 * beta +
+                 alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2 +
+                          alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta +
+                                   alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
+    const double prefactor_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
+    const double prefactor_den = 12960.0 * alpha * alpha * alpha * b2 * (1.0 + 12.0 * total);
+    return prefactor_num / (1.0 - x) * poly / prefactor_den;
+  }
+  const double prefactor = -x / sqrt(2.0 * alpha * beta / total);
+  const double stirling = (1.0 + 1.0 / (12.0 * alpha) + 1.0 / (288.0 * alpha * alpha)) *
+                          (1.0 + 1.0 / (12.0 * beta) + 1.0 / (288.0 * beta * beta)) /
+                          (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
+  const double term1_num = 2.0 * (alpha * alpha) * (x - 1.0) + alpha * beta * (x - 1.0) - x * (beta * beta);
+  const double axbx = alpha * (x - 1.0) + beta * x;
+  const double term1_den = sqrt(2.0 * alpha / beta) * pow(total, 1.5) * axbx * axbx;
+  const double term1 = term1_num / term1_den;
+  const double term2 = 0.5 * log(alpha / (total * x));
+  const double term3_num = sqrt(8.0 * alpha * beta / total);
+  const double term3_den = beta * x + alpha * (x - 1.0);
+  const double term3 = term3_num / term3_den;
+  const double term4_base = beta * log(beta / (total * (1.0 - x))) + alpha * log(alpha / (total * x));
+  const double term4 = pow(term4_base, -1.5);
+  const double term1234 = term1 + term2 * (term3 + (x < mean ? term4 : -term4));
+  return stirling * prefactor * term1234;
+}
+
+TQ_HD float tq_dirichlet_grad(float x_, float alpha_, float total_) {
+  const double x = x_, alpha = alpha_, total = total_;
+  const double beta = total - alpha;
+  const double boundary = total * x * (1.0 - x);
+  if (x <= 0.5 && boundary < 2.5) return (float)tq_beta_grad_alpha_small(x, alpha, beta);
+  if (x >= 0.5 && boundary < 0.75) return (float)(-tq_beta_grad_beta_small(1.0 - x, beta, alpha));
+  if (alpha > 6.0 && beta > 6.0) return (float)tq_beta_grad_alpha_mid(x, alpha, beta);
+  // rational correction to an analytic approximation; coefficients: PyTorch (BSD-3)
+  const double c[2][3][3][4] = {
+      {{{1.003668233, -0.01061107488, -0.0657888334, 0.01201642863},
+        {0.6336835991, -0.3557432599, 0.05486251648, -0.001465281033},
+        {-0.03276231906, 0.004474107445, 0.002429354597, -0.0001557569013}},
+       {{0.221950385, -0.3187676331, 0.01799915743, 0.01074823814},
+        {-0.2951249643, 0.06219954479, 0.01535556598, 0.001550077057},
+        {0.02155310298, 0.004170831599, 0.001292462449, 6.976601077e-05}},
+       {{-0.05980841433, 0.008441916499, 0.01085618172, 0.002319392565},
+        {0.02911413504, 0.01400243777, -0.002721828457, 0.000751041181},
+        {0.005900514878, -0.001936558688, -9.495446725e-06, 5.385558597e-05}}},
+      {{{1, -0.02924021934, -0.04438342661, 0.007285809825},
+        {0.6357567472, -0.3473456711, 0.05454656494, -0.002407477521},
+        {-0.03301322327, 0.004845219414, 0.00231480583, -0.0002307248149}},
+       {{0.5925320577, -0.1757678135, 0.01505928619, 0.000564515273},
+        {0.1014815858, -0.06589186703, 0.01272886114, -0.0007316646956},
+        {-0.007258481865, 0.001096195486, 0.0003934994223, -4.12701925e-05}},
+       {{0.06469649321, -0.0236701437, 0.002902096474, -5.896963079e-05},
+        {0.001925008108, -0.002869809258, 0.0008000589141, -6.063713228e-05},
+        {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}},
+  };
+  const double u = log(x);
+  const double a = log(alpha) - u;
+  const double b = log(total) - a;
+  const double pow_u[3] = {1.0, u, u * u};
+  const double pow_a[3] = {1.0, a, a * a};
+  double p = 0.0, q = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double ua = pow_u[i] * pow_a[j];
+      p += ua * (c[0][i][j][0] + b * (c[0][i][j][1] + b * (c[0][i][j][2] + b * c[0][i][j][3])));
+      q += ua * (c[1][i][j][0] + b * (c[1][i][j][1] + b * (c[1][i][j][2] + b * c[1][i][j][3])));
+    }
+  const double approx = x * (tq_digamma_d(total) - tq_digamma_d(alpha)) / beta;
+  return (float)(p / q * approx);
+}

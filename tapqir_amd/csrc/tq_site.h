@@ -1,0 +1,349 @@
+// tq_site.h -- everything in one SVI step of the cosmos model that is per unit (AOI n, frame f,
+// channel c) but NOT per pixel (host+device inline; used by tq_cosmos.hip and tests/hostcheck).
+//
+// Reference semantics (tapqir/models/cosmos.py:82-462 under pyro TraceEnum_ELBO; SURVEY.md
+// Appendix A.3).  For one unit, with Dice weights W(m) = prod_k q(m_k), m in {0,1}^K:
+//
+//   E_u = log Gamma(b; (mu_b/sigma_b)^2, mu_b/sigma_b^2) - log q(b)
+//       + sum_m W(m) { ll(m) + L(m) + sum_k m_k T_k - sum_k log q(m_k) }
+//   T_k = log HalfNormal(h_k; height_std) + log U(w_k; w_min, w_max)
+//         - log q(h_k) - log q(w_k) - log q(x_k) - log q(y_k)
+//   L(m) = log[ (1-rho) A_0(m) + (rho/K) sum_k' A_k'(m) ]            (z, theta summed out)
+//   A_theta(m) = prod_k Bern(m_k; pm[theta,k]) [p(x_k|theta) p(y_k|theta)]^{m_k}
+//
+// and the gradient of w_u * E_u (w_u = plate scale * AOI mask) with respect to the unit's
+// 8K+2 unconstrained variational parameters, the AOI's background_mean/std parameters and the
+// global latents (rho, a(lamda), c(lamda), c_s(proximity)); the pixel part (ll(m) and its
+// pathwise gradients) comes from tq_ksmogn.hip.
+//
+// Reparameterisation: Gamma(alpha=loc*beta, beta) draws are g/beta with g ~ Gamma(alpha,1);
+// AffineBeta draws are low + scale * t, t ~ Beta(c1,c0), clamped to [low+eps*scale,
+// high-eps*scale] (pyro AffineBeta.rsample).  d g/d alpha and d t/d c are the implicit
+// gradients of tq_math.h, exactly the functions torch.autograd uses for the reference.
+#pragma once
+#include "tq_math.h"
+
+#define TQ_MAXK 4
+#define TQ_MAXQ 4
+
+// number of per-unit unconstrained local parameters: 8 per spot + 2
+#define TQ_NLOCAL(K) (8 * (K) + 2)
+// row order of the local parameter block [TQ_NLOCAL][U]  (spot rows are k-major within a name)
+enum { TQ_P_MPROBS = 0, TQ_P_HLOC = 1, TQ_P_HBETA = 2, TQ_P_WMEAN = 3, TQ_P_WSIZE = 4, TQ_P_XMEAN = 5, TQ_P_YMEAN = 6, TQ_P_SIZE = 7 };
+#define TQ_ROW(name, k, K) ((name) * (K) + (k))
+#define TQ_ROW_BLOC(K) (8 * (K))
+#define TQ_ROW_BBETA(K) (8 * (K) + 1)
+
+// per-step global latents and tables derived from them (written by the globals kernel)
+struct TqGlobals {
+  float gain, proximity;
+  float cs;       // per-axis concentration of the target-specific position prior: ((H/sigma)^2 - 1)/2
+  // The symmetric Beta(cs, cs) density in t is written against 4 t (1-t) (<= 1, = 1 at the centre):
+  //   ln Beta(t; cs, cs) = (cs-1) ln[4 t (1-t)] - lnBp,   lnBp = ln B(cs,cs) + 2 (cs-1) ln 2  (= O(ln cs))
+  // so the O(cs) terms (cs-1) ln[t(1-t)] and ln B(cs,cs), which cancel, are never formed in fp32.
+  float lnB_s;    // lnBp
+  float dlnB_s;   // d lnBp / d cs = 2 psi(cs) - 2 psi(2 cs) + 2 ln 2  (= O(1/cs))
+  float lamda[TQ_MAXQ];
+  float rho[TQ_MAXQ];       // pi_q[1]
+  float a[TQ_MAXQ];         // probs_m[q, theta=0, k]
+  float c[TQ_MAXQ];         // probs_m[q, theta=k'+1, k != k']   (K >= 2)
+};
+
+struct TqSiteConsts {
+  float H;            // (P+1)/2
+  float eps;          // finfo(model dtype).eps used in the interval bounds and the rsample clamp
+  float w_lo, w_hi;   // priors width_min / width_max
+  float height_std;
+  float bg_mean_std, bg_std_std;  // only used by the AOI kernel
+};
+
+// ---- log-densities with derivatives ---------------------------------------------------------------
+// Gamma(v; alpha = loc*beta, rate = beta) in the cancellation-free form (see tq_pixel.h):
+//   = -ln v + alpha phi(v/loc) + (1/2) ln alpha - ln sqrt(2pi) - S(alpha)
+TQ_HD void tq_gamma_logpdf(float v, float loc, float beta, float* lp, float* d_v, float* d_alpha, float* d_beta) {
+  const float alpha = loc * beta;
+  const float rho = v / loc;
+  const float lrho = log1pf((v - loc) / loc);
+  const float lna = logf(alpha), ra = 1.0f / alpha;
+  float S, dS;
+  tq_binet(alpha, lna, ra, &S, &dS);
+  *lp = -logf(v) + alpha * (lrho + 1.0f - rho) + 0.5f * lna - TQ_LN_SQRT_2PI - S;
+  *d_v = (alpha - 1.0f) / v - beta;
+  *d_alpha = lrho + 0.5f * ra - dS;  // = ln beta + ln v - digamma(alpha)
+  *d_beta = loc - v;                 // = alpha / beta - v
+}
+
+// Beta(t; c1, c0)
+TQ_HD void tq_beta_logpdf(float t, float c1, float c0, float* lp, float* d_t, float* d_c1, float* d_c0) {
+  const float lt = logf(t), l1t = log1pf(-t);
+  float lg1, dg1, lg0, dg0, lgt, dgt;
+  tq_lgamma_digamma(c1, &lg1, &dg1);
+  tq_lgamma_digamma(c0, &lg0, &dg0);
+  tq_lgamma_digamma(c1 + c0, &lgt, &dgt);
+  *lp = (c1 - 1.0f) * lt + (c0 - 1.0f) * l1t + lgt - lg1 - lg0;
+  *d_t = (c1 - 1.0f) / t - (c0 - 1.0f) / (1.0f - t);
+  *d_c1 = lt - dg1 + dgt;
+  *d_c0 = l1t - dg0 + dgt;
+}
+
+// One AffineBeta(mean, size, low, high) guide site evaluated at the (possibly clamped) draw y.
+//   e_y   : total derivative of the objective w.r.t. y coming from everything else
+//   wq    : weight of -log q(y) in the objective (w_u * q(m_k = 1))
+// returns lq and accumulates d objective / d mean, d size (constrained parameters)
+TQ_HD float tq_affine_beta_site(float y, float mean, float size, float low, float high, float eps, float e_y,
+                                float wq, float* d_mean, float* d_size, float* d_lq_dy) {
+  const float sc = high - low;
+  const float t = (y - low) / sc;
+  const float c1 = size * (mean - low) / sc;
+  const float c0 = size * (high - mean) / sc;
+  float lq, d_t, d_c1, d_c0;
+  tq_beta_logpdf(t, c1, c0, &lq, &d_t, &d_c1, &d_c0);
+  lq -= logf(sc);
+  const float dlq_dy = d_t / sc;
+  *d_lq_dy = dlq_dy;
+  // pathwise: y = low + sc * t unless clamped by rsample
+  const bool clamped = (y <= low + eps * sc) || (y >= high - eps * sc);
+  const float ey_tot = e_y - wq * dlq_dy;
+  float dy_dc1 = 0.0f, dy_dc0 = 0.0f;
+  if (!clamped) {
+    dy_dc1 = sc * tq_dirichlet_grad(t, c1, size) * (1.0f - t);
+    dy_dc0 = -sc * tq_dirichlet_grad(1.0f - t, c0, size) * t;
+  }
+  const float g_c1 = ey_tot * dy_dc1 - wq * d_c1;
+  const float g_c0 = ey_tot * dy_dc0 - wq * d_c0;
+  *d_mean = (g_c1 - g_c0) * size / sc;
+  *d_size = g_c1 * (mean - low) / sc + g_c0 * (high - mean) / sc;
+  return lq;
+}
+
+// One Gamma(loc*beta, beta) guide site evaluated at draw v = g / beta.
+TQ_HD float tq_gamma_site(float v, float loc, float beta, float e_v, float wq, float* d_loc_u, float* d_beta_u) {
+  float lq, d_v, d_alpha, d_beta;
+  tq_gamma_logpdf(v, loc, beta, &lq, &d_v, &d_alpha, &d_beta);
+  const float alpha = loc * beta;
+  const float ev_tot = e_v - wq * d_v;
+  const float dv_dalpha = tq_std_gamma_grad(alpha, v * beta) / beta;
+  const float g_alpha = ev_tot * dv_dalpha - wq * d_alpha;
+  const float g_beta_direct = ev_tot * (-v / beta) - wq * d_beta;
+  // alpha = loc*beta; loc = exp(u_loc), beta = exp(u_beta)
+  *d_loc_u = g_alpha * alpha;
+  *d_beta_u = g_alpha * alpha + g_beta_direct * beta;
+  return lq;
+}
+
+// ---- inputs / outputs of the per-unit routine ---------------------------------------------------
+template <int K>
+struct TqUnitIn {
+  float u[TQ_NLOCAL(K)];   // unconstrained local parameters, row order above
+  float u_bml, u_bsl;      // unconstrained background_mean_loc / background_std_loc of the AOI
+  float b, h[K], w[K], x[K], y[K];  // latent draws
+  float ll[1 << K];        // unweighted pixel log-likelihood per combination
+  float gb, gh[K], gw[K], gx[K], gy[K];  // pathwise pixel gradients, already times w_u W(m)
+  float wu;                // plate scale * mask
+  int on;                  // is_ontarget
+  int q;                   // dye / channel index
+};
+
+template <int K>
+struct TqUnitOut {
+  float g[TQ_NLOCAL(K)];   // d (w_u E_u) / d unconstrained local parameters
+  float g_bml, g_bsl;      // contribution to d/d u_background_mean_loc, d/d u_background_std_loc
+  float d_rho, d_a, d_c, d_cs;  // d (w_u E_u) / d global tables
+  float elbo;              // w_u E_u
+};
+
+template <int K>
+TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSiteConsts& C, TqUnitOut<K>* out) {
+  constexpr int M = 1 << K;
+  const float wu = in.wu;
+  const float H = C.H, eps = C.eps;
+  const int q = in.q;
+
+  // ---- q(m_k) ------------------------------------------------------------------------------------
+  float p1[K], p0[K], lp1[K], lp0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float uk = in.u[TQ_ROW(TQ_P_MPROBS, k, K)];
+    p1[k] = tq_sigmoid(uk);
+    p0[k] = tq_sigmoid(-uk);
+    lp1[k] = -tq_softplus(-uk);
+    lp0[k] = -tq_softplus(uk);
+  }
+
+  // ---- z / theta marginal L(m) and its derivatives -----------------------------------------------
+  const float rho = in.on ? G.rho[q] : 0.0f;
+  const float a = G.a[q], c = G.c[q];
+  const float ln_a = logf(a), ln_1ma = log1pf(-a);
+  const float ln_c = (K > 1) ? logf(c) : 0.0f, ln_1mc = (K > 1) ? log1pf(-c) : 0.0f;
+  const float ln_1mrho = log1pf(-rho);
+  const float ln_rhoK = in.on ? logf(rho / (float)K) : -INFINITY;
+  const float lu = -2.0f * logf(2.0f * H);  // log uniform density of (x, y) on (-H, H)^2
+  const float cs = G.cs;
+  float tsum[K], sxy[K], dsx[K], dsy[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float tx = (in.x[k] + H) / (2.0f * H), ty = (in.y[k] + H) / (2.0f * H);
+    const float ex = 2.0f * tx - 1.0f, ey = 2.0f * ty - 1.0f;
+    tsum[k] = log1pf(-ex * ex) + log1pf(-ey * ey);  // ln[4 tx (1-tx)] + ln[4 ty (1-ty)]
+    sxy[k] = (cs - 1.0f) * tsum[k] - 2.0f * G.lnB_s + lu;
+    dsx[k] = (cs - 1.0f) * (1.0f / tx - 1.0f / (1.0f - tx)) / (2.0f * H);
+    dsy[k] = (cs - 1.0f) * (1.0f / ty - 1.0f / (1.0f - ty)) / (2.0f * H);
+  }
+
+  float Lm[M], Wm[M];
+  float d_rho = 0.0f, d_a = 0.0f, d_c = 0.0f, dS[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) dS[k] = 0.0f;
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) {
+    int n1 = 0;
+    float w = 1.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      n1 += (mi >> k) & 1;
+      w *= ((mi >> k) & 1) ? p1[k] : p0[k];
+    }
+    Wm[mi] = w;
+    const float fn1 = (float)n1, fn0 = (float)(K - n1);
+    float T[K + 1];
+    T[0] = ln_1mrho + fn1 * ln_a + fn0 * ln_1ma + fn1 * lu;
+    float mx = T[0];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (((mi >> k) & 1) && in.on) {
+        T[k + 1] = ln_rhoK + sxy[k] + (fn1 - 1.0f) * lu + fn0 * ln_1mc;
+        if (K > 1 && n1 > 1) T[k + 1] += (fn1 - 1.0f) * ln_c;
+      } else {
+        T[k + 1] = -INFINITY;
+      }
+      mx = fmaxf(mx, T[k + 1]);
+    }
+    float se = 0.0f, r[K + 1];
+#pragma unroll
+    for (int th = 0; th <= K; ++th) {
+      r[th] = expf(T[th] - mx);
+      se += r[th];
+    }
+    Lm[mi] = mx + logf(se);
+    const float rse = 1.0f / se;
+#pragma unroll
+    for (int th = 0; th <= K; ++th) r[th] *= rse;
+    // derivatives of L(m), weighted by the Dice weight
+    d_a += w * r[0] * (fn1 / a - fn0 / (1.0f - a));
+    float rsum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      rsum += r[k + 1];
+      dS[k] += w * r[k + 1];
+    }
+    if (K > 1) d_c += w * rsum * ((fn1 - 1.0f) / c - fn0 / (1.0f - c));
+    if (in.on) d_rho += w * (-r[0] / (1.0f - rho) + rsum / rho);
+  }
+
+  // ---- per-spot continuous sites -----------------------------------------------------------------
+  float Tk[K];
+  const float w_sc = C.w_hi - C.w_lo;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float wq = wu * p1[k];
+    float lq, d_lq;
+    // height: prior HalfNormal(height_std), guide Gamma(h_loc*h_beta, h_beta)
+    const float hl = expf(in.u[TQ_ROW(TQ_P_HLOC, k, K)]), hb = expf(in.u[TQ_ROW(TQ_P_HBETA, k, K)]);
+    const float hs = C.height_std;
+    const float lp_h = TQ_LN2 - logf(hs) - TQ_LN_SQRT_2PI - in.h[k] * in.h[k] / (2.0f * hs * hs);
+    const float e_h = in.gh[k] + wq * (-in.h[k] / (hs * hs));
+    lq = tq_gamma_site(in.h[k], hl, hb, e_h, wq, &out->g[TQ_ROW(TQ_P_HLOC, k, K)], &out->g[TQ_ROW(TQ_P_HBETA, k, K)]);
+    float t_k = lp_h - lq;
+    // width: prior uniform on (w_lo, w_hi), guide AffineBeta(w_mean, w_size, w_lo, w_hi)
+    {
+      const float sg = tq_sigmoid(in.u[TQ_ROW(TQ_P_WMEAN, k, K)]);
+      const float lo = C.w_lo + eps, hi = C.w_hi - eps;
+      const float mean = lo + (hi - lo) * sg;
+      const float ex = expf(in.u[TQ_ROW(TQ_P_WSIZE, k, K)]);
+      float d_mean, d_size;
+      lq = tq_affine_beta_site(in.w[k], mean, 2.0f + ex, C.w_lo, C.w_hi, eps, in.gw[k], wq, &d_mean, &d_size, &d_lq);
+      out->g[TQ_ROW(TQ_P_WMEAN, k, K)] = d_mean * (hi - lo) * sg * (1.0f - sg);
+      out->g[TQ_ROW(TQ_P_WSIZE, k, K)] = d_size * ex;
+      t_k += -logf(w_sc) - lq;
+    }
+    // x, y: guide AffineBeta(mean, size, -H, H); model-side dependence through L(m)
+    {
+      const float ex = expf(in.u[TQ_ROW(TQ_P_SIZE, k, K)]);
+      const float size = 2.0f + ex;
+      const float lo = -H + eps, hi = H - eps;
+      const float sgx = tq_sigmoid(in.u[TQ_ROW(TQ_P_XMEAN, k, K)]);
+      const float sgy = tq_sigmoid(in.u[TQ_ROW(TQ_P_YMEAN, k, K)]);
+      float d_mean, d_size_x, d_size_y;
+      const float e_x = in.gx[k] + wu * dS[k] * dsx[k];
+      const float e_y = in.gy[k] + wu * dS[k] * dsy[k];
+      lq = tq_affine_beta_site(in.x[k], lo + (hi - lo) * sgx, size, -H, H, eps, e_x, wq, &d_mean, &d_size_x, &d_lq);
+      out->g[TQ_ROW(TQ_P_XMEAN, k, K)] = d_mean * (hi - lo) * sgx * (1.0f - sgx);
+      t_k -= lq;
+      lq = tq_affine_beta_site(in.y[k], lo + (hi - lo) * sgy, size, -H, H, eps, e_y, wq, &d_mean, &d_size_y, &d_lq);
+      out->g[TQ_ROW(TQ_P_YMEAN, k, K)] = d_mean * (hi - lo) * sgy * (1.0f - sgy);
+      t_k -= lq;
+      out->g[TQ_ROW(TQ_P_SIZE, k, K)] = (d_size_x + d_size_y) * ex;
+    }
+    Tk[k] = t_k;
+  }
+
+  // ---- Dice expectation over m and the gradient w.r.t. the m_probs logits --------------------------
+  float Esum = 0.0f, gm[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) gm[k] = 0.0f;
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) {
+    float inner = in.ll[mi] + Lm[mi];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int mk = (mi >> k) & 1;
+      inner += mk ? (Tk[k] - lp1[k]) : -lp0[k];
+    }
+    const float wi = Wm[mi] * inner;
+    // W(m) = 0 with inner = -inf (impossible image under m that the guide also excludes) must not give NaN
+    const float term = (Wm[mi] == 0.0f) ? 0.0f : wi;
+    Esum += term;
+#pragma unroll
+    for (int k = 0; k < K; ++k) gm[k] += term * ((float)((mi >> k) & 1) - p1[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) out->g[TQ_ROW(TQ_P_MPROBS, k, K)] = wu * gm[k];
+
+  // ---- background: prior Gamma((mu_b/sigma_b)^2, mu_b/sigma_b^2), guide Gamma(b_loc*b_beta, b_beta) ---
+  {
+    const float mub = expf(in.u_bml), sgb = expf(in.u_bsl);
+    const float r0 = mub / (sgb * sgb);
+    float lp_b, d_v, d_alpha, d_beta;
+    tq_gamma_logpdf(in.b, mub, r0, &lp_b, &d_v, &d_alpha, &d_beta);  // loc = a0/r0 = mu_b
+    const float a0 = mub * r0;
+    // a0 = mu^2/sigma^2, r0 = mu/sigma^2 ; d/d ln mu and d/d ln sigma
+    out->g_bml = wu * (d_alpha * 2.0f * a0 + d_beta * r0);
+    out->g_bsl = wu * (d_alpha * -2.0f * a0 + d_beta * -2.0f * r0);
+    const float bl = expf(in.u[TQ_ROW_BLOC(K)]), bb = expf(in.u[TQ_ROW_BBETA(K)]);
+    const float e_b = in.gb + wu * d_v;
+    const float lq_b = tq_gamma_site(in.b, bl, bb, e_b, wu, &out->g[TQ_ROW_BLOC(K)], &out->g[TQ_ROW_BBETA(K)]);
+    Esum += lp_b - lq_b;
+  }
+
+  // ---- global-table partials ---------------------------------------------------------------------
+  float d_cs = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) d_cs += dS[k] * (tsum[k] - 2.0f * G.dlnB_s);
+  out->d_rho = wu * d_rho;
+  out->d_a = wu * d_a;
+  out->d_c = wu * d_c;
+  out->d_cs = wu * d_cs;
+  out->elbo = wu * Esum;
+}
+
+// ---- per-AOI prior terms (cosmos.py:221-227): HalfNormal(mu_b; s1) + HalfNormal(sigma_b; s2) ------
+TQ_HD void tq_cosmos_aoi(float u_bml, float u_bsl, float w_n, const TqSiteConsts& C, float* elbo, float* g_bml,
+                         float* g_bsl) {
+  const float mub = expf(u_bml), sgb = expf(u_bsl);
+  const float s1 = C.bg_mean_std, s2 = C.bg_std_std;
+  const float lp = 2.0f * (TQ_LN2 - TQ_LN_SQRT_2PI) - logf(s1) - logf(s2) - mub * mub / (2.0f * s1 * s1) -
+                   sgb * sgb / (2.0f * s2 * s2);
+  *elbo = w_n * lp;
+  *g_bml = w_n * (-mub / (s1 * s1)) * mub;
+  *g_bsl = w_n * (-sgb / (s2 * s2)) * sgb;
+}

@@ -1,0 +1,191 @@
+"""
+``cosmos`` -- multi-colour time-independent colocalisation model, drop-in for
+tapqir/models/cosmos.py:28-784 on AMD MI355X.
+
+The probabilistic program of the reference (``model`` 82-327, ``guide`` 329-462 under pyro's
+``TraceEnum_ELBO``) is not traced here: its closed-form ELBO is evaluated,
+differentiated and optimised by hand-written HIP kernels (``tapqir_amd/csrc``) through the C ABI in
+``include/tapqir_hip.h``.  Parameter names, shapes, constraints and initial values are those of
+``init_parameters`` / ``_init_parameters`` (464-598); checkpoints use the reference's key set.
+"""
+
+import math
+
+import torch
+
+from tapqir_amd.models.engine import DEFAULT_PRIORS, CosmosEngine
+from tapqir_amd.models.model import Model
+
+
+def initial_values(eng, data):
+    """Constrained initial values, cosmos.py:471-598."""
+    K, Nt, F, C = eng.K, eng.Nt, eng.F, eng.C
+    Q = C
+    f = lambda shape, v: torch.full(shape, float(v), dtype=torch.float64)
+    images = data.images
+    med = torch.stack([torch.median(images[..., c, :, :].reshape(-1)[:50_000_000]) for c in range(C)]).double().cpu()
+    bg = (med - data.offset.mean).clamp(min=1e-3)
+    return {
+        "pi_mean": torch.full((Q, 2), 0.5, dtype=torch.float64),  # ones -> softmax -> uniform (Appendix B.5)
+        "pi_size": f((Q, 1), 2), "m_probs": f((K, Nt, F, Q), 0.5),
+        "proximity_loc": f((), 0.5), "proximity_size": f((), 100),
+        "lamda_loc": f((Q,), 0.5), "lamda_beta": f((Q,), 100),
+        "gain_loc": f((), 5), "gain_beta": f((), 100),
+        "background_mean_loc": bg.expand(Nt, 1, C), "background_std_loc": f((Nt, 1, C), 1),
+        "b_loc": bg.expand(Nt, F, C), "b_beta": f((Nt, F, C), 1),
+        "h_loc": f((K, Nt, F, Q), 2000), "h_beta": f((K, Nt, F, Q), 0.001),
+        "w_mean": f((K, Nt, F, Q), 1.5), "w_size": f((K, Nt, F, Q), 100),
+        "x_mean": f((K, Nt, F, Q), 0), "y_mean": f((K, Nt, F, Q), 0), "size": f((K, Nt, F, Q), 200),
+    }
+
+
+class _HipTraceEnumELBO:
+    """Stand-in for ``pyro.infer.TraceEnum_ELBO(max_plate_nesting=3)`` (cosmos.py:600-607): the
+    object ``Model.init`` keeps as ``self.elbo``.  ``loss`` / ``loss_and_grads`` evaluate -ELBO of a
+    fresh minibatch with the HIP kernels (gradients land in ``engine.grad``)."""
+
+    def __init__(self, model, max_plate_nesting=3):
+        self._m = model
+        self.max_plate_nesting = max_plate_nesting
+
+    def loss_and_grads(self, model=None, guide=None, *args, **kwargs):
+        m = self._m
+        eng = m.engine
+        ndx, fdx = m._subsample()
+        a = eng.make_args(ndx, fdx)
+        for name in ("cosmos_sample_globals", "cosmos_sample_locals", "cosmos_elbo_grads", "cosmos_globals_grad"):
+            eng.call(name, a)
+        return -float(eng.elbo_out.item())
+
+    loss = loss_and_grads
+    differentiable_loss = loss_and_grads
+
+
+class cosmos(Model):
+    r"""
+    **Multi-Color Time-Independent Colocalization Model** (cosmos.py:28-45).
+
+    :param K: Maximum number of spots that can be present in a single image.
+    :param device: Computation device; the SVI step requires ``"cuda"`` (= HIP on ROCm).
+    :param dtype: accepted for compatibility ("double"/"float"); kernels compute in float32.
+    :param use_pykeops: accepted and ignored (the fused HIP kernel replaces the KeOps reduction).
+    :param priors: Dictionary of parameters of prior distributions.
+    """
+
+    name = "cosmos"
+
+    def __init__(self, S: int = 1, K: int = 2, Q: int = None, device: str = "cpu", dtype: str = "double",
+                 use_pykeops: bool = True, priors: dict = None):
+        if S != 1:
+            raise NotImplementedError("cosmos supports S=1 molecular state (cosmos.py:251 clamps z to {0,1})")
+        priors = dict(DEFAULT_PRIORS) if priors is None else priors
+        super().__init__(S=S, K=K, Q=Q, device=device, dtype=dtype, priors=priors)
+        self._global_params = ["gain", "proximity", "lamda", "pi"]
+        self.use_pykeops = use_pykeops
+        self.conv_params = ["-ELBO", "proximity_loc", "gain_loc", "lamda_loc"]
+        self.ci_params = ["gain", "pi", "lamda", "proximity", "background", "height", "width", "x", "y"]
+        self._subsample_gen = torch.Generator().manual_seed(0)
+        self._probs = None
+        self.allreduce = None  # set by tapqir_amd.parallel for AOI-sharded data parallelism
+
+    # -- descriptions of the probabilistic program (no tracing happens) ---------------------------
+    def model(self):
+        """Generative model: see cosmos.py:82-327; evaluated in closed form by the HIP kernels."""
+        raise NotImplementedError("the generative model is fused into the HIP step; see DESIGN.md")
+
+    def guide(self):
+        """Variational family: see cosmos.py:329-462; sampled by tq_cosmos_sample_* kernels."""
+        raise NotImplementedError("the guide is fused into the HIP step; see DESIGN.md")
+
+    def TraceELBO(self, jit=False):
+        return _HipTraceEnumELBO(self, max_plate_nesting=3)
+
+    # -- engine / parameters -------------------------------------------------------------------------
+    def _make_engine(self, **kw):
+        if self.engine is None:
+            self.engine = CosmosEngine(self.data, K=self.K, priors=self.priors, device=self.device, **kw)
+        return self.engine
+
+    def init_parameters(self):
+        """cosmos.py:464-598."""
+        eng = self._make_engine()
+        eng.layout.set_constrained(eng.params, initial_values(eng, self.data))
+        eng.exp_avg.zero_()
+        eng.exp_avg_sq.zero_()
+        eng.grad.zero_()
+        eng.adam_step = 0
+
+    # -- one SVI step ----------------------------------------------------------------------------------
+    def _subsample(self):
+        """pyro.plate(size, subsample_size): randperm(size)[:subsample_size], identity when equal
+        (cosmos.py:194-208; Appendix B.2); ``self.n`` / ``self.f`` fix the subsample (197, 205)."""
+        d = self.data
+        nb = self.nbatch_size or d.Nt
+        fb = self.fbatch_size or d.F
+        if self.n is not None:
+            ndx = torch.as_tensor(self.n)
+        elif nb >= d.Nt:
+            ndx = None
+        else:
+            ndx = torch.randperm(d.Nt, generator=self._subsample_gen)[:nb]
+        if self.f is not None:
+            fdx = torch.as_tensor(self.f)
+        elif fb >= d.F:
+            fdx = None
+        else:
+            fdx = torch.randperm(d.F, generator=self._subsample_gen)[:fb]
+        return ndx, fdx
+
+    def step_async(self) -> None:
+        """One SVI update, nothing read back (the -ELBO stays on the device)."""
+        ndx, fdx = self._subsample()
+        self.engine.step(ndx, fdx, allreduce=self.allreduce)
+        self._probs = None
+
+    def last_loss(self) -> float:
+        return -float(self.engine.elbo_out.item())
+
+    def step(self) -> float:
+        """Replaces ``self.svi.step()`` (model.py:212): applies one Adam update and returns the
+        minibatch -ELBO; raises ValueError on a non-finite loss so that ``run``'s recovery path
+        (model.py:220-232) works."""
+        self.step_async()
+        loss = self.last_loss()
+        if not math.isfinite(loss):
+            raise ValueError(f"Iteration #{getattr(self, 'iter', 0)}. Non-finite loss {loss}")
+        return loss
+
+    # -- posteriors (cosmos.py:609-709) ------------------------------------------------------------------
+    @property
+    def m_probs(self) -> torch.Tensor:
+        r"""Posterior spot presence probability :math:`q(m=1)`."""
+        return torch.sigmoid(self.engine.named("params")["m_probs"]).detach()
+
+    @property
+    def compute_probs(self):
+        if self._probs is None:
+            from tapqir_amd.models.posterior import compute_probs
+
+            self._probs = compute_probs(self)
+        return self._probs
+
+    @property
+    def z_probs(self) -> torch.Tensor:
+        r"""Probability of there being a target-specific spot :math:`p(z=1)`."""
+        return self.compute_probs[0]
+
+    @property
+    def theta_probs(self) -> torch.Tensor:
+        r"""Posterior target-specific spot probability :math:`q(\theta = k)`."""
+        return self.compute_probs[1]
+
+    @property
+    def pspecific(self) -> torch.Tensor:
+        return self.z_probs
+
+    @property
+    def z_map(self) -> torch.Tensor:
+        return torch.argmax(self.z_probs, dim=-1)
+
+
+Cosmos = cosmos  # notebooks/part_iii_colab.ipynb:98 imports the capitalised spelling

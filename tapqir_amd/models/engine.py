@@ -1,0 +1,167 @@
+"""
+Device-side state of a cosmos fit and the launcher of the HIP step.
+
+Owns what the reference keeps in Pyro's global param store + ``pyro.optim.Adam`` state
+(tapqir/models/model.py:153-186): the flat unconstrained parameter buffer, its gradient and the
+two Adam moments, the dataset resident in HBM (the reference re-uploads every minibatch,
+tapqir/utils/dataset.py:140-151) and the step workspace.  All arithmetic happens in
+``libtapqir_hip.so`` (include/tapqir_hip.h); torch is used for allocation, streams and the
+``torch.distributed`` all-reduce only.
+"""
+
+import ctypes as C
+import math
+
+import torch
+
+from tapqir_amd import _lib
+from tapqir_amd.exceptions import HipExtensionError
+from tapqir_amd.models.layout import ParamLayout
+
+DEFAULT_PRIORS = {  # tapqir/models/cosmos.py:55-64
+    "background_mean_std": 1000.0, "background_std_std": 100.0, "lamda_rate": 1.0, "height_std": 10000.0,
+    "width_min": 0.75, "width_max": 2.25, "proximity_rate": 1.0, "gain_std": 50.0,
+}
+
+
+def merge_offsets(samples, weights):
+    """Offset samples with equal value are one mixture component: sum_o w_o f(D - d_o) is
+    unchanged when equal d_o are merged (simulate.py:92-103 stores 3 identical samples)."""
+    s = samples.detach().double().cpu()
+    w = weights.detach().double().cpu()
+    uniq, inv = torch.unique(s, return_inverse=True)
+    wsum = torch.zeros_like(uniq).index_add_(0, inv, w)
+    eps = torch.finfo(torch.float64).eps
+    logits = torch.log(wsum.clamp(eps, 1 - eps)) if len(uniq) > 1 else torch.log(wsum.clamp(min=eps))
+    return uniq.float(), logits.float()
+
+
+class CosmosEngine:
+    def __init__(self, data, K=2, priors=None, device="cuda", eps=None, seed=0, lib=None,
+                 n_offset=0, Nt_global=None):
+        self.device = torch.device(device)
+        self._hostcheck = lib is not None
+        if lib is None:
+            if self.device.type != "cuda":
+                raise HipExtensionError(
+                    "the cosmos SVI step only runs on an AMD GPU through libtapqir_hip.so "
+                    f"(device={device!r} requested); there is no CPU path")
+            lib = _lib.load()
+        self.lib = lib
+        self.K = int(K)
+        self.priors = dict(DEFAULT_PRIORS if priors is None else priors)
+        self.eps = float(torch.finfo(torch.float32).eps if eps is None else eps)
+        self.seed = int(seed)
+        Nt, F, Cc, P = data.images.shape[:4]
+        self.Nt, self.F, self.C, self.P = int(Nt), int(F), int(Cc), int(P)
+        self.Nt_global = int(Nt_global) if Nt_global else self.Nt
+        self.n_offset = int(n_offset)
+        dev = self.device
+        f32 = torch.float32
+        self.images = data.images.to(dev, f32).contiguous()
+        self.xy = data.xy.to(dev, f32).contiguous()
+        self.is_ontarget = data.is_ontarget.to(dev, torch.uint8).contiguous()
+        self.mask = data.mask.to(dev, torch.uint8).contiguous()
+        off_s, off_l = merge_offsets(data.offset.samples, data.offset.weights)
+        self.offset_samples, self.offset_logits = off_s.to(dev), off_l.to(dev)
+        self.O = int(off_s.numel())
+        self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps)
+        n = self.layout.total
+        self.params = torch.zeros(n, dtype=f32, device=dev)
+        self.grad = torch.zeros(n, dtype=f32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
+        gsz = int(lib.hc_globals_size() if self._hostcheck else lib.tq_globals_size())
+        bsz = int(lib.hc_gbase_size() if self._hostcheck else lib.tq_gbase_size())
+        self.globals = torch.zeros(gsz // 4, dtype=f32, device=dev)
+        self.gbase = torch.zeros(bsz // 8, dtype=torch.float64, device=dev)
+        self.gsum = torch.zeros(3 + 3 * self.C, dtype=torch.float64, device=dev)
+        self.elbo_out = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._ws_key = None
+        self.adam_step = 0
+        self.lr, self.betas, self.adam_eps = 0.005, (0.9, 0.999), 1e-8
+
+    # -- workspace ---------------------------------------------------------------------------------
+    def _workspace(self, nb, fb):
+        key = (nb, fb)
+        if self._ws_key == key:
+            return
+        K, M = self.K, 1 << self.K
+        B = nb * fb * self.C
+        dev, f32 = self.device, torch.float32
+        self.lat = torch.zeros((1 + 4 * K) * B, dtype=f32, device=dev)
+        self.pix = torch.zeros((M + 2 + 4 * K) * B, dtype=f32, device=dev)
+        self.aoi_part = torch.zeros(3 * B, dtype=f32, device=dev)
+        nblk = (B + 255) // 256
+        self.blk_part = torch.zeros(nblk * (3 + 3 * self.C), dtype=f32, device=dev)
+        self._ws_key = key
+
+    def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None):
+        nb = self.Nt if ndx is None else int(ndx.numel())
+        fb = self.F if fdx is None else int(fdx.numel())
+        self._workspace(nb, fb)
+        if ndx is not None:
+            ndx = ndx.to(self.device, torch.int32).contiguous()
+        if fdx is not None:
+            fdx = fdx.to(self.device, torch.int32).contiguous()
+        self._keep = (ndx, fdx)  # keep index tensors alive while kernels run
+        p = _lib.ptr
+        a = _lib.CosmosArgs()
+        a.images, a.xy, a.is_ontarget, a.aoi_mask = p(self.images), p(self.xy), p(self.is_ontarget), p(self.mask)
+        a.ndx, a.fdx = p(ndx), p(fdx)
+        a.offset_samples, a.offset_logits = p(self.offset_samples), p(self.offset_logits)
+        a.params, a.grad, a.exp_avg, a.exp_avg_sq = p(self.params), p(self.grad), p(self.exp_avg), p(self.exp_avg_sq)
+        a.lat, a.pix, a.aoi_part, a.blk_part = p(self.lat), p(self.pix), p(self.aoi_part), p(self.blk_part)
+        a.gsum, a.globals, a.gbase, a.elbo_out = p(self.gsum), p(self.globals), p(self.gbase), p(self.elbo_out)
+        a.Nt, a.F, a.C, a.P, a.K, a.O = self.Nt, self.F, self.C, self.P, self.K, self.O
+        a.nb, a.fb, a.n_offset, a.draw_globals = nb, fb, self.n_offset, int(bool(draw_globals))
+        a.scale_n = self.Nt_global / self._nb_global(nb)
+        a.scale = a.scale_n * self.F / fb
+        a.global_weight = global_weight
+        a.eps = self.eps
+        pr = self.priors
+        a.width_min, a.width_max, a.height_std = pr["width_min"], pr["width_max"], pr["height_std"]
+        a.background_mean_std, a.background_std_std = pr["background_mean_std"], pr["background_std_std"]
+        a.gain_std, a.lamda_rate, a.proximity_rate = pr["gain_std"], pr["lamda_rate"], pr["proximity_rate"]
+        t = self.adam_step + 1
+        a.lr, a.beta1, a.beta2, a.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
+        a.bias_correction1 = 1.0 - self.betas[0] ** t
+        a.bias_correction2 = 1.0 - self.betas[1] ** t
+        a.zero_grad = int(nb < self.Nt or fb < self.F)
+        a.seed = self.seed
+        a.step = self.adam_step if step is None else int(step)
+        return a
+
+    def _nb_global(self, nb):
+        # AOI sharding: every rank subsamples nb local AOIs of Nt local ones, so the global
+        # subsample is nb * (Nt_global / Nt)
+        return nb * self.Nt_global / self.Nt
+
+    # -- launches ------------------------------------------------------------------------------------
+    def _stream(self):
+        return None if self._hostcheck else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def call(self, name, args):
+        if self._hostcheck:
+            getattr(self.lib, "hc_" + name)(C.byref(args))
+        else:
+            _lib.check(getattr(self.lib, "tq_" + name)(C.byref(args), self._stream()), "tq_" + name)
+
+    def step(self, ndx=None, fdx=None, allreduce=None):
+        """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``)."""
+        a = self.make_args(ndx, fdx)
+        if allreduce is None and not self._hostcheck:
+            self.call("cosmos_step", a)
+        else:
+            self.call("cosmos_sample_globals", a)
+            self.call("cosmos_sample_locals", a)
+            self.call("cosmos_elbo_grads", a)
+            if allreduce is not None:
+                allreduce(self.gsum)
+            self.call("cosmos_globals_grad", a)
+            self.call("cosmos_adam", a)
+        self.adam_step += 1
+
+    # -- named views -----------------------------------------------------------------------------------
+    def named(self, which="params"):
+        return self.layout.views(getattr(self, which))

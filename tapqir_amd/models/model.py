@@ -1,0 +1,305 @@
+"""
+Model driver of the drop-in surface (mirrors tapqir/models/model.py:31-371: same method names,
+arguments, attributes, files and error behaviour).  ``self.svi.step()`` of the reference
+(model.py:212) is ``self.step()`` here, executed by the HIP library through ``CosmosEngine``.
+"""
+
+import logging
+import random
+from collections import defaultdict, deque
+from pathlib import Path
+from typing import Union
+
+import torch
+
+from tapqir_amd.exceptions import CudaOutOfMemoryError, TapqirFileNotFoundError
+from tapqir_amd.utils.dataset import load
+
+logger = logging.getLogger(__name__)
+
+try:  # tensorboard is optional glue (model.py:209, 284-298)
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:  # pragma: no cover
+    SummaryWriter = None
+
+
+class _NullWriter:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_scalars(self, *a, **k):
+        pass
+
+
+def _is_oom(err):
+    msg = str(err.args[0]) if err.args else ""
+    return msg.startswith("CUDA out of memory") or msg.startswith("HIP out of memory") or "out of memory" in msg
+
+
+class Model:
+    r"""
+    Base class for tapqir models (model.py:31-48).  Derived models implement ``init_parameters``
+    and ``step`` (the reference's ``model`` / ``guide`` / ``TraceELBO`` are Pyro programs; the
+    equivalents here are descriptions of, and handles on, the fused HIP step).
+    """
+
+    name = "model"
+
+    def __init__(self, S: int = 1, K: int = 2, Q: int = None, device: str = "cpu", dtype: str = "double",
+                 priors: dict = None):
+        self.S = S
+        self.K = K
+        self._Q = Q
+        self.nbatch_size = None
+        self.fbatch_size = None
+        self.priors = priors
+        self.n = None
+        self.f = None
+        self.data_path = None
+        self.path = None
+        self.run_path = None
+        self.engine = None
+        self.to(device, dtype)
+
+    def to(self, device: str, dtype: str = "double") -> None:
+        """model.py:75-91.  ``dtype`` is accepted for API compatibility; the HIP kernels compute
+        in float32 with float64 cross-unit sums (the reference's `tapqir fit` uses float64,
+        main.py:428) and no global default tensor type is changed."""
+        self.dtype = getattr(torch, dtype)
+        self.device = torch.device(device)
+
+    @property
+    def Q(self):
+        return self._Q or self.data.C
+
+    def load(self, path: Union[str, Path], data_only: bool = True) -> None:
+        """model.py:97-127."""
+        self.path = Path(path)
+        self.run_path = self.path / ".tapqir"
+        self.data = load(self.path, self.device)
+        logger.debug(f"Loaded data from {self.path / 'data.tpqr'}")
+        if not data_only:
+            try:
+                self.params = torch.load(self.path / f"{self.name}_params.tpqr", weights_only=False)
+            except FileNotFoundError:
+                raise TapqirFileNotFoundError("parameter", self.path / f"{self.name}_params.tpqr")
+            try:
+                import pandas as pd
+
+                self.summary = pd.read_csv(self.path / f"{self.name}_summary.csv", index_col=0)
+            except FileNotFoundError:
+                raise TapqirFileNotFoundError("summary", self.path / f"{self.name}_summary.csv")
+
+    # -- subclass hooks ---------------------------------------------------------------------------
+    def model(self):
+        raise NotImplementedError
+
+    def guide(self):
+        raise NotImplementedError
+
+    def TraceELBO(self, jit=False):
+        raise NotImplementedError
+
+    def init_parameters(self):
+        raise NotImplementedError
+
+    def _make_engine(self):
+        raise NotImplementedError
+
+    def step(self) -> float:
+        raise NotImplementedError
+
+    # -- model.py:153-186 ---------------------------------------------------------------------------
+    def init(self, lr: float = 0.005, nbatch_size: int = 5, fbatch_size: int = 512, jit: bool = False) -> None:
+        self.lr = lr
+        self.optim_args = {"lr": lr, "betas": [0.9, 0.999]}
+        self._make_engine()
+        self.engine.lr, self.engine.betas = lr, (0.9, 0.999)
+        try:
+            self.load_checkpoint()
+        except TapqirFileNotFoundError:
+            self.iter = 0
+            self.converged = False
+            self._rolling = defaultdict(lambda: deque([], maxlen=100))
+            self.init_parameters()
+        self.elbo = self.TraceELBO(jit)
+        self.nbatch_size = min(nbatch_size, self.data.Nt)
+        self.fbatch_size = min(fbatch_size, self.data.F)
+
+    # -- model.py:188-237 ---------------------------------------------------------------------------
+    def run(self, num_iter: int = 0, progress_bar=None) -> None:
+        use_crit = False
+        if not num_iter:
+            use_crit = True
+            num_iter = 100000
+        if progress_bar is None:
+            try:
+                from tqdm import tqdm as progress_bar
+            except Exception:  # pragma: no cover
+                progress_bar = lambda x: x
+        logger.debug("Model - {}".format(self.name))
+        logger.debug("Device - {}".format(self.device))
+        logger.debug("Learning rate - {}".format(self.lr))
+        logger.debug("AOI batch size - {}".format(self.nbatch_size))
+        logger.debug("Frame batch size - {}".format(self.fbatch_size))
+        writer_cm = _NullWriter()
+        if SummaryWriter is not None and self.run_path is not None:
+            try:
+                writer_cm = SummaryWriter(log_dir=self.run_path / "logs" / self.name)
+            except Exception:  # pragma: no cover
+                writer_cm = _NullWriter()
+        with writer_cm as writer:
+            for i in progress_bar(range(num_iter)):
+                try:
+                    # checkpoint iterations need the loss on the host; the others stay asynchronous
+                    if not self.iter % 200:
+                        self.iter_loss = self.step()
+                        self.save_checkpoint(writer)
+                        if use_crit and self.converged:
+                            logger.info(f"Iteration #{self.iter} model converged.")
+                            break
+                    else:
+                        self.step_async()
+                    self.iter += 1
+                except ValueError:
+                    # load last checkpoint, change rng seed (model.py:220-232)
+                    self.init(lr=self.lr, nbatch_size=self.nbatch_size, fbatch_size=self.fbatch_size)
+                    new_seed = random.randint(0, 100)
+                    self.set_rng_seed(new_seed)
+                    logger.warning(f"Iteration #{self.iter} restarting with a new seed: {new_seed}.")
+                except RuntimeError as err:
+                    if _is_oom(err):
+                        raise CudaOutOfMemoryError()
+                    raise
+            else:
+                logger.warning(f"Iteration #{self.iter} model has not converged.")
+        self.iter_loss = self.last_loss()
+
+    def set_rng_seed(self, seed):
+        self.engine.seed = int(seed)
+        self._subsample_gen = torch.Generator().manual_seed(int(seed))
+
+    # -- model.py:239-323 ---------------------------------------------------------------------------
+    def named_params(self):
+        """dict name -> unconstrained leaf tensor (view into the engine's flat buffer)."""
+        return self.engine.named("params")
+
+    def save_checkpoint(self, writer=None):
+        eng = self.engine
+        # save only if no NaN values (model.py:245-250)
+        if not bool(torch.isfinite(eng.params).all()):
+            for k, v in self.named_params().items():
+                if not bool(torch.isfinite(v).all()):
+                    raise ValueError("Iteration #{}. Detected NaN values in {}".format(self.iter, k))
+        cparams = eng.layout.constrained(eng.params)
+        for name in self.conv_params:
+            if name == "-ELBO":
+                self._rolling["-ELBO"].append(self.iter_loss)
+            elif cparams[name].ndim == 1:
+                for i in range(len(cparams[name])):
+                    self._rolling[f"{name}_{i}"].append(cparams[name][i].item())
+            else:
+                self._rolling[name].append(cparams[name].item())
+        # convergence (model.py:258-270)
+        self.converged = False
+        if len(self._rolling["-ELBO"]) == self._rolling["-ELBO"].maxlen:
+            crit = all(
+                torch.tensor(value).std() / torch.tensor(value)[-50:].std() < 1.05 for value in self._rolling.values()
+            )
+            if crit:
+                self.converged = True
+        if self.run_path is not None:
+            self.run_path.mkdir(parents=True, exist_ok=True)
+            torch.save(
+                {
+                    "iter": self.iter,
+                    "params": self._param_store_state(),
+                    "optimizer": self._optim_state(),
+                    "rolling": dict(self._rolling),
+                    "convergence_status": self.converged,
+                },
+                self.run_path / f"{self.name}_model.tpqr",
+            )
+        if writer is not None:
+            writer.add_scalar("-ELBO", self.iter_loss, self.iter)
+            for name, val in cparams.items():
+                if val.dim() == 0:
+                    writer.add_scalar(name, val.item(), self.iter)
+                elif val.dim() == 1 and len(val) <= self.Q * 2:
+                    writer.add_scalars(name, {str(i): v.item() for i, v in enumerate(val)}, self.iter)
+                elif val.dim() == 2 and len(val) <= self.Q * 2:
+                    writer.add_scalars(
+                        name, {f"{i}_{j}": k.item() for i, v in enumerate(val) for j, k in enumerate(v)}, self.iter)
+        logger.debug(f"Iteration #{self.iter}: Successful.")
+
+    def _param_store_state(self):
+        """Same payload shape as pyro.get_param_store().get_state()."""
+        cons = self.engine.layout.constraints()
+        return {
+            "params": {n: v.detach().cpu().clone() for n, v in self.named_params().items()},
+            "constraints": {n: cons[n] for n in self.named_params()},
+        }
+
+    def _optim_state(self):
+        """Same payload shape as pyro.optim.PyroOptim.get_state(): name -> torch Adam state_dict."""
+        eng = self.engine
+        m, v = eng.named("exp_avg"), eng.named("exp_avg_sq")
+        out = {}
+        for n in m:
+            out[n] = {
+                "state": {0: {"step": torch.tensor(float(eng.adam_step)), "exp_avg": m[n].detach().cpu().clone(),
+                              "exp_avg_sq": v[n].detach().cpu().clone()}},
+                "param_groups": [{"lr": eng.lr, "betas": tuple(eng.betas), "eps": eng.adam_eps, "weight_decay": 0,
+                                  "amsgrad": False, "maximize": False, "params": [0]}],
+            }
+        return out
+
+    # -- model.py:325-357 ---------------------------------------------------------------------------
+    def load_checkpoint(self, path: Union[str, Path] = None, param_only: bool = False, warnings: bool = False):
+        path = Path(path) if path else self.run_path
+        if path is None:
+            raise TapqirFileNotFoundError("model", f"{self.name}_model.tpqr")
+        model_path = path / f"{self.name}_model.tpqr"
+        try:
+            checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+        except FileNotFoundError:
+            raise TapqirFileNotFoundError("model", model_path)
+        if self.engine is None:
+            self._make_engine()
+        eng = self.engine
+        views = eng.named("params")
+        for n, t in checkpoint["params"]["params"].items():
+            views[n].copy_(t.reshape(views[n].shape).to(eng.params.dtype))
+        if not param_only:
+            self.converged = checkpoint["convergence_status"]
+            self._rolling = defaultdict(lambda: deque([], maxlen=100), checkpoint["rolling"])
+            self.iter = checkpoint["iter"]
+            m, v = eng.named("exp_avg"), eng.named("exp_avg_sq")
+            step = 0
+            for n, sd in checkpoint["optimizer"].items():
+                st = sd["state"][0]
+                m[n].copy_(st["exp_avg"].reshape(m[n].shape).to(eng.params.dtype))
+                v[n].copy_(st["exp_avg_sq"].reshape(v[n].shape).to(eng.params.dtype))
+                step = int(st["step"])
+            eng.adam_step = step
+            logger.info(f"Iteration #{self.iter}. Loaded a model checkpoint from {model_path}")
+        if warnings and not checkpoint["convergence_status"]:
+            logger.warning(f"Model at {path} has not been fully trained")
+
+    # -- model.py:359-371 ---------------------------------------------------------------------------
+    def compute_stats(self, CI: float = 0.95, save_matlab: bool = False):
+        from tapqir_amd.utils.stats import save_stats
+
+        try:
+            save_stats(self, self.path, CI=CI, save_matlab=save_matlab)
+        except RuntimeError as err:
+            if _is_oom(err):
+                raise CudaOutOfMemoryError()
+            raise
+        logger.debug("Computing stats: Successful.")

@@ -1,0 +1,240 @@
+// hostcheck.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the host+device inline math of tapqir_amd/csrc (tq_math.h, tq_pixel.h, tq_site.h,
+// tq_globals.h, tq_bodies.h) with g++ and drives it with plain loops on HOST memory, so the
+// CPU test-suite can check the hand-derived gradients against the oracle without a GPU.
+// The product (tapqir_amd/_lib.py) never loads this library; there is no CPU fallback.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../tapqir_amd/csrc/tq_bodies.h"
+#include "../../tapqir_amd/csrc/tq_pixel.h"
+
+extern "C" {
+
+void hc_lgamma_digamma(const float* a, float* lg, float* dg, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) tq_lgamma_digamma(a[i], &lg[i], &dg[i]);
+}
+void hc_std_gamma_grad(const float* alpha, const float* x, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = tq_std_gamma_grad(alpha[i], x[i]);
+}
+void hc_dirichlet_grad(const float* x, const float* alpha, const float* total, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = tq_dirichlet_grad(x[i], alpha[i], total[i]);
+}
+void hc_sample_std_gamma(uint64_t seed, uint32_t step, uint32_t site, const float* alpha, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    TqPhilox s;
+    tq_philox_init(&s, seed, step, site, (uint64_t)i);
+    out[i] = tq_sample_std_gamma(&s, alpha[i]);
+  }
+}
+void hc_philox(uint64_t seed, uint32_t step, uint32_t site, uint64_t elem, uint32_t* out, int n) {
+  TqPhilox s;
+  tq_philox_init(&s, seed, step, site, elem);
+  for (int i = 0; i < n; ++i) out[i] = tq_philox_next(&s);
+}
+void hc_mean_frac(double lam, int K, double* val, double* dval) { tq_mean_frac(lam, K, val, dval); }
+
+}  // extern "C"
+
+// Host emulation of tq_ksmogn_kernel (same per-pixel functions, plain loops).
+template <int K>
+static void ksmogn_host(const tq_ksmogn_args& a) {
+  constexpr int M = 1 << K;
+  const int64_t B = (int64_t)a.nb * a.fb * a.C;
+  const int P = a.P, npix = P * P;
+  const bool bwd = a.g_background != nullptr;
+  const float g = a.gain[0], rg = 1.0f / g, ln_g = logf(g);
+  for (int64_t i = 0; i < B; ++i) {
+    const int c = (int)(i % a.C);
+    const int64_t ab = i / a.C;
+    const int bi = (int)(ab % a.fb), ai = (int)(ab / a.fb);
+    const int n = a.ndx ? a.ndx[ai] : ai, f = a.fdx ? a.fdx[bi] : bi;
+    const int64_t u = ((int64_t)n * a.F + f) * a.C + c;
+    const float tx = a.xy[2 * u], ty = a.xy[2 * u + 1], b = a.background[i];
+    float hk[K], wk[K], amp[K], cx[K], cy[K], inv2v[K];
+    for (int k = 0; k < K; ++k) {
+      hk[k] = a.height[k * B + i];
+      wk[k] = a.width[k * B + i];
+      cx[k] = a.x[k * B + i] + tx;
+      cy[k] = a.y[k * B + i] + ty;
+      inv2v[k] = 0.5f / (wk[k] * wk[k]);
+      amp[k] = inv2v[k] * (1.0f / TQ_PI);
+    }
+    float W[M];
+    if (bwd) {
+      if (a.gout) {
+        for (int mi = 0; mi < M; ++mi) W[mi] = a.gout[(int64_t)mi * B + i];
+      } else {
+        const float sc = a.scale * ((a.aoi_mask == nullptr || a.aoi_mask[n]) ? 1.0f : 0.0f);
+        for (int mi = 0; mi < M; ++mi) {
+          float w = sc;
+          for (int k = 0; k < K; ++k) {
+            const float uk = a.m_logit[k * a.m_kstride + u];
+            w *= ((mi >> k) & 1) ? tq_sigmoid(uk) : tq_sigmoid(-uk);
+          }
+          W[mi] = w;
+        }
+      }
+    }
+    double ll[M] = {0}, acc_b = 0, acc_g = 0, S0[K] = {0}, S1x[K] = {0}, S1y[K] = {0}, S2[K] = {0};
+    for (int pix = 0; pix < npix; ++pix) {
+      const int j = pix / P, ic = pix % P;
+      const float D = a.images[u * npix + pix];
+      float spotn[K], dx[K], dy[K];
+      for (int k = 0; k < K; ++k) {
+        dx[k] = (float)ic - cx[k];
+        dy[k] = (float)j - cy[k];
+        spotn[k] = amp[k] * expf(-dx[k] * dx[k] * inv2v[k]) * expf(-dy[k] * dy[k] * inv2v[k]);
+      }
+      float lp[M], da[M], gq[M];
+      for (int mi = 0; mi < M; ++mi) {
+        float mu = b;
+        for (int k = 0; k < K; ++k)
+          if ((mi >> k) & 1) mu += hk[k] * spotn[k];
+        if (a.O == 1) {
+          const float v = D - a.offset_samples[0];
+          if (v > 0.0f) tq_pix_one_offset(v, logf(v), a.offset_logits[0], mu, rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
+          else { lp[mi] = -INFINITY; da[mi] = 0; gq[mi] = 0; }
+        } else {
+          TqComboPix cp;
+          TqLse acc;
+          tq_combo_prepare(mu, rg, g, ln_g, &cp);
+          tq_lse_init(&acc);
+          for (int o = 0; o < a.O; ++o) {
+            const float v = D - a.offset_samples[o];
+            if (v > 0.0f) {
+              const float lv = logf(v);
+              tq_lse_push(&acc, cp, v, lv, a.offset_logits[o] - lv);
+            }
+          }
+          tq_lse_finish(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
+        }
+        ll[mi] += lp[mi];
+      }
+      if (bwd) {
+        float q[K];
+        for (int k = 0; k < K; ++k) q[k] = 0;
+        for (int mi = 0; mi < M; ++mi) {
+          const float cw = W[mi] * da[mi];
+          acc_b += cw;
+          acc_g += W[mi] * gq[mi];
+          for (int k = 0; k < K; ++k)
+            if ((mi >> k) & 1) q[k] += cw;
+        }
+        for (int k = 0; k < K; ++k) {
+          const float aq = q[k] * spotn[k];
+          S0[k] += aq;
+          S1x[k] += aq * dx[k];
+          S1y[k] += aq * dy[k];
+          S2[k] += aq * (dx[k] * dx[k] + dy[k] * dy[k]);
+        }
+      }
+    }
+    for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = (float)ll[mi];
+    if (bwd) {
+      a.g_background[i] = (float)(acc_b * rg);
+      a.g_gain[i] = (float)(-acc_g * rg);
+      for (int k = 0; k < K; ++k) {
+        const float rw = 1.0f / wk[k], hs = hk[k] * rg;
+        a.g_height[k * B + i] = (float)(S0[k] * rg);
+        a.g_x[k * B + i] = (float)(hs * S1x[k] * rw * rw);
+        a.g_y[k * B + i] = (float)(hs * S1y[k] * rw * rw);
+        a.g_width[k * B + i] = (float)(hs * (S2[k] * rw * rw * rw - 2.0 * S0[k] * rw));
+      }
+    }
+  }
+}
+
+extern "C" {
+
+int hc_ksmogn_log_prob(const tq_ksmogn_args* a) {
+  switch (a->K) {
+    case 1: ksmogn_host<1>(*a); break;
+    case 2: ksmogn_host<2>(*a); break;
+    case 3: ksmogn_host<3>(*a); break;
+    default: ksmogn_host<4>(*a); break;
+  }
+  return 0;
+}
+
+int64_t hc_globals_size(void) { return (int64_t)sizeof(TqGlobals); }
+int64_t hc_gbase_size(void) { return (int64_t)sizeof(TqGlobalBase); }
+
+void hc_cosmos_sample_globals(const tq_cosmos_args* a) { tq_body_sample_globals(*a); }
+void hc_cosmos_sample_locals(const tq_cosmos_args* a) {
+  const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
+  for (int64_t t = 0; t < total; ++t) tq_body_sample_local(*a, t);
+}
+
+}  // extern "C"
+
+template <int K>
+static void units_host(const tq_cosmos_args& a, double* sums) {
+  const int64_t B = tq_batch_units(a);
+  const int nq = 3 + 3 * a.C;
+  float part[3 + 3 * TQ_MAXQ];
+  for (int64_t i = 0; i < B; ++i) {
+    tq_body_unit<K>(a, i, part);
+    for (int j = 0; j < nq; ++j) sums[j] += part[j];
+  }
+}
+
+extern "C" {
+
+void hc_cosmos_elbo_grads(const tq_cosmos_args* a) {
+  const int K = a->K, M = 1 << K;
+  const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
+  tq_ksmogn_args k;
+  memset(&k, 0, sizeof(k));
+  k.images = a->images; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
+  k.background = a->lat;
+  k.height = a->lat + (int64_t)1 * B;
+  k.width = a->lat + (int64_t)(1 + K) * B;
+  k.x = a->lat + (int64_t)(1 + 2 * K) * B;
+  k.y = a->lat + (int64_t)(1 + 3 * K) * B;
+  k.gain = &((const TqGlobals*)a->globals)->gain;
+  k.offset_samples = a->offset_samples; k.offset_logits = a->offset_logits;
+  k.m_logit = a->params; k.m_kstride = U; k.aoi_mask = a->aoi_mask;
+  k.ll = a->pix;
+  k.g_background = a->pix + (int64_t)M * B;
+  k.g_gain = a->pix + (int64_t)(M + 1) * B;
+  k.g_height = a->pix + (int64_t)(M + 2) * B;
+  k.g_width = a->pix + (int64_t)(M + 2 + K) * B;
+  k.g_x = a->pix + (int64_t)(M + 2 + 2 * K) * B;
+  k.g_y = a->pix + (int64_t)(M + 2 + 3 * K) * B;
+  k.nb = a->nb; k.fb = a->fb; k.C = a->C; k.F = a->F; k.P = a->P; k.K = K; k.O = a->O;
+  k.scale = a->scale;
+  hc_ksmogn_log_prob(&k);
+  const int nq = 3 + 3 * a->C;
+  std::vector<double> sums(nq, 0.0);
+  switch (K) {
+    case 1: units_host<1>(*a, sums.data()); break;
+    case 2: units_host<2>(*a, sums.data()); break;
+    case 3: units_host<3>(*a, sums.data()); break;
+    default: units_host<4>(*a, sums.data()); break;
+  }
+  for (int ai = 0; ai < a->nb; ++ai)
+    for (int c = 0; c < a->C; ++c) {
+      double s1 = 0, s2 = 0;
+      for (int b = 0; b < a->fb; ++b) {
+        const int64_t i = ((int64_t)ai * a->fb + b) * a->C + c;
+        s1 += a->aoi_part[i];
+        s2 += a->aoi_part[B + i];
+      }
+      float e;
+      tq_body_aoi_finish(*a, ai, c, (float)s1, (float)s2, &e);
+      sums[TQ_GS_ELBO] += e;
+    }
+  for (int j = 0; j < nq; ++j) a->gsum[j] = sums[j];
+}
+
+void hc_cosmos_globals_grad(const tq_cosmos_args* a) { tq_body_globals_grad(*a); }
+void hc_cosmos_adam(const tq_cosmos_args* a) {
+  const int64_t total = (int64_t)TQ_NLOCAL(a->K) * tq_num_units(*a) + 2 * (int64_t)a->Nt * a->C + TQ_NGLOBAL(a->C);
+  for (int64_t j = 0; j < total; ++j) tq_body_adam(*a, j);
+}
+
+}  // extern "C"

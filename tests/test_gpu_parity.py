@@ -1,0 +1,160 @@
+"""
+Parity of the HIP path (through the C ABI of libtapqir_hip.so) against the CPU oracle, on a
+real MI355X.  Tolerance: north_star asks for 1e-4 relative (fp32); the assertions are tighter
+where the formulation allows.
+"""
+
+import ctypes as C
+
+import pytest
+import torch
+
+from helpers import (CosmosEngine, fp32_latents, load_hostcheck, make_dataset, make_oracle, oracle_grads,
+                     oracle_to_engine, put_latents, read_engine_latents, rel_err)
+from test_hostcheck_parity import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case_gpu(dkw, K, ndx, fdx, perturb=0.3):
+    d = make_dataset(K=K, **dkw)
+    o = make_oracle(d, K, perturb=perturb)
+    eng = CosmosEngine(d, K=K, device="cuda:0")
+    oracle_to_engine(o, eng)
+    nd = torch.arange(d.images.shape[0]) if ndx is None else torch.tensor(ndx)
+    fd = torch.arange(d.images.shape[1]) if fdx is None else torch.tensor(fdx)
+    lat32, base = fp32_latents(o, nd, fd)
+    elbo_o, g_o = oracle_grads(o, nd, fd, base)
+    a = eng.make_args(None if ndx is None else nd, None if fdx is None else fd, draw_globals=False)
+    put_latents(eng, lat32, base)
+    eng.call("cosmos_sample_globals", a)
+    eng.call("cosmos_elbo_grads", a)
+    eng.call("cosmos_globals_grad", a)
+    torch.cuda.synchronize()
+    return o, eng, elbo_o, g_o
+
+
+@pytest.mark.parametrize("name,dkw,K,ndx,fdx", CASES, ids=[c[0] for c in CASES])
+def test_elbo_and_gradients_match_oracle(name, dkw, K, ndx, fdx):
+    o, eng, elbo_o, g_o = run_case_gpu(dkw, K, ndx, fdx)
+    elbo_k = float(eng.elbo_out[0])
+    assert abs(elbo_k - elbo_o) <= 1e-5 * abs(elbo_o), (elbo_k, elbo_o)
+    gv = eng.named("grad")
+    for n, ref in g_o.items():
+        got = gv[n].cpu().double().reshape(ref.shape)
+        assert rel_err(got, ref) < 1e-4, (n, rel_err(got, ref))
+
+
+def test_log_likelihood_per_combination():
+    o, eng, _, _ = run_case_gpu(dict(N=3, F=4), 2, None, None)
+    B = 12
+    ll_k = eng.pix[: 4 * B].view(4, B).cpu().double()
+    ll_o = o.last_terms["ll"].detach().reshape(4, B)
+    assert rel_err(ll_k, ll_o) < 2e-6
+
+
+def test_device_matches_host_build_of_same_math():
+    """The gfx950 build and the g++ build of the same inline math agree (fast intrinsics vs libm)."""
+    hc = load_hostcheck()
+    d = make_dataset(N=3, F=5, K=2)
+    o = make_oracle(d, 2)
+    outs = []
+    for dev, lib in (("cuda:0", None), ("cpu", hc)):
+        eng = CosmosEngine(d, K=2, device=dev, lib=lib)
+        oracle_to_engine(o, eng)
+        nd, fd = torch.arange(3), torch.arange(5)
+        lat32, base = fp32_latents(o, nd, fd)
+        a = eng.make_args(draw_globals=False)
+        put_latents(eng, lat32, base)
+        for name in ("cosmos_sample_globals", "cosmos_elbo_grads", "cosmos_globals_grad"):
+            eng.call(name, a)
+        outs.append((eng.grad.cpu().double(), float(eng.elbo_out[0])))
+    torch.cuda.synchronize()
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[1][1])
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-4
+
+
+def test_sampler_statistics_and_host_agreement():
+    """Guide draws on the device: (i) same Philox streams as the host build, (ii) right moments."""
+    hc = load_hostcheck()
+    d = make_dataset(N=8, F=64, K=2)
+    o = make_oracle(d, 2, perturb=0.2)
+    draws = []
+    for dev, lib in (("cuda:0", None), ("cpu", hc)):
+        eng = CosmosEngine(d, K=2, device=dev, lib=lib, seed=123)
+        oracle_to_engine(o, eng)
+        a = eng.make_args()
+        eng.call("cosmos_sample_globals", a)
+        eng.call("cosmos_sample_locals", a)
+        draws.append((eng.lat.cpu().double(), eng.gbase.cpu().clone()))
+    torch.cuda.synchronize()
+    dev_lat, host_lat = draws[0][0], draws[1][0]
+    same = ((dev_lat - host_lat).abs() <= 1e-4 * host_lat.abs() + 1e-6).double().mean()
+    assert same > 0.99, same  # rare rejection-test flips from fast-math are allowed
+    assert torch.allclose(draws[0][1], draws[1][1], rtol=1e-4, atol=1e-6)
+    # moments of b ~ Gamma(b_loc * b_beta, b_beta): mean b_loc, var b_loc / b_beta
+    B = 8 * 64
+    cp = {n: v.detach() for n, v in o.constrained(o.params).items()}
+    b = dev_lat[:B].view(8, 64, 1)
+    z = (b - cp["b_loc"]) / (cp["b_loc"] / cp["b_beta"]).sqrt()
+    assert abs(float(z.mean())) < 4 / B**0.5 * 1.5
+    assert abs(float(z.var()) - 1) < 0.25
+    # x ~ AffineBeta(x_mean, size, -H, H): mean x_mean
+    H = 7.5
+    x = dev_lat[(1 + 4) * B:(1 + 6) * B].view(2, 8, 64, 1)
+    sd = ((cp["x_mean"] + H) * (H - cp["x_mean"]) / (cp["size"] + 1)).sqrt()
+    zx = (x - cp["x_mean"]) / sd
+    assert abs(float(zx.mean())) < 4 / (2 * B) ** 0.5 * 1.5
+    assert abs(float(zx.var()) - 1) < 0.25
+
+
+def test_adam_matches_torch():
+    d = make_dataset(N=2, F=3, K=2)
+    eng = CosmosEngine(d, K=2, device="cuda:0")
+    g = torch.Generator().manual_seed(0)
+    n = eng.params.numel()
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=0.005, betas=(0.9, 0.999))
+    eng.params.copy_(p0)
+    for it in range(5):
+        grad = torch.randn(n, generator=g) * (10.0 ** torch.randint(-3, 4, (n,), generator=g).float())
+        eng.grad.copy_(grad)  # grad holds d ELBO / d param; Adam descends on -ELBO
+        a = eng.make_args()
+        eng.call("cosmos_adam", a)
+        eng.adam_step += 1
+        ref.grad = -grad.double()
+        opt.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(eng.params.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("minibatch", [False, True])
+def test_full_step_trajectory(minibatch):
+    """Three complete HIP steps (device sampling + Adam); the oracle replays each step with the
+    device's own draws and its own autograd + torch.optim.Adam."""
+    K, N, F = 2, 4, 6
+    d = make_dataset(N=N, F=F, K=K)
+    o = make_oracle(d, K, perturb=0.0)
+    o.make_optim(lr=0.005)
+    eng = CosmosEngine(d, K=K, device="cuda:0", seed=11)
+    oracle_to_engine(o, eng)
+    g = torch.Generator().manual_seed(5)
+    for it in range(3):
+        nd = torch.randperm(N, generator=g)[:3] if minibatch else torch.arange(N)
+        fd = torch.randperm(F, generator=g)[:4] if minibatch else torch.arange(F)
+        eng.step(nd if minibatch else None, fd if minibatch else None)
+        torch.cuda.synchronize()
+        lat32 = read_engine_latents(eng, len(nd), len(fd))
+        with torch.no_grad():
+            base = o.base_draws(lat32, o._guide_dists(o.constrained(o.params), nd, fd))
+        loss_o = o.step(nd, fd, base=base)
+        assert abs(-float(eng.elbo_out[0]) - loss_o) <= 2e-5 * abs(loss_o)
+        views = eng.named("params")
+        for n, u in o.params.items():
+            got = views[n].cpu().double().reshape(u.shape)
+            # Adam's first steps move every parameter by ~lr regardless of gradient scale, so
+            # compare the updates absolutely: 2 % of one step
+            assert (got - u.detach()).abs().max() < 1e-4, (it, n, float((got - u.detach()).abs().max()))
+        # keep both sides on identical parameters for the next step
+        oracle_to_engine(o, eng)
