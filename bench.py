@@ -48,6 +48,9 @@ def time_pixel_kernel(eng, launches, backward):
     from tapqir_amd import _lib
 
     a = eng.make_args()
+    # fresh guide draws in the (possibly re-allocated) full-batch workspace
+    eng.call("cosmos_sample_globals", a)
+    eng.call("cosmos_sample_locals", a)
     K, M = eng.K, 1 << eng.K
     B = eng.Nt * eng.F * eng.C
     k = _lib.KsmognArgs()
@@ -85,13 +88,24 @@ def cpu_baseline(data, K, nb, fb, steps=3, warmup=1):
     """Oracle (dense torch float64 = the tensor program Pyro would run) on the host cores."""
     from oracle.cosmos import CosmosOracle, OracleData
 
-    torch.set_num_threads(os.cpu_count())
     od = OracleData(data.images[:nb, :fb].cpu(), data.xy[:nb, :fb].cpu(), data.is_ontarget[:nb].cpu(),
                     data.offset.samples.cpu(), data.offset.weights.cpu())
     o = CosmosOracle(od, K=K)
     o.init_parameters()
     o.make_optim(lr=0.005)
     nd, fd = torch.arange(nb), torch.arange(fb)
+    # torch's intra-op pool does not scale to hundreds of host threads on these tensor sizes:
+    # take the thread count that runs this step fastest (one probe step each) and say which it was
+    best = None
+    for nt in sorted({t for t in (8, 16, 32, 64, os.cpu_count()) if t <= os.cpu_count()}):
+        torch.set_num_threads(nt)
+        o.step(nd, fd)
+        t0 = time.perf_counter()
+        o.step(nd, fd)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    torch.set_num_threads(best[1])
     ts = []
     for it in range(warmup + steps):
         t0 = time.perf_counter()
@@ -100,7 +114,8 @@ def cpu_baseline(data, K, nb, fb, steps=3, warmup=1):
             ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"value": nb * fb / med, "unit": "AOI-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": nb * fb / med, "unit": "AOI-frames/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"oracle dense-torch float64 full SVI step, nb={nb} x fb={fb} units of the same data, "
                       f"median of {steps} steps after {warmup} warm-up ({med:.2f} s/step = {1 / med:.3f} steps/s)",
             "steps_per_sec_at_sample": 1 / med}

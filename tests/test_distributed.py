@@ -1,0 +1,95 @@
+"""
+AOI-sharded data parallelism, world_size 2 over gloo on the CPU.  The ranks drive the g++ host
+build of the kernels' math (tests/hostcheck) -- the arithmetic is not what is under test here; the
+sharding, the global-index RNG keys, the plate scales and the position of the single all-reduce are.
+"""
+
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import CosmosEngine, load_hostcheck, make_dataset, make_oracle, oracle_to_engine
+    from tapqir_amd.parallel import make_allreduce, shard_dataset
+
+    hc = load_hostcheck()
+    K, N, F = 2, 6, 5
+    d = make_dataset(N=N, F=F, K=K)
+    o = make_oracle(d, K, perturb=0.2)
+    sub, n_off, Nt_global = shard_dataset(d, rank, world)
+    eng = CosmosEngine(sub, K=K, device="cpu", lib=hc, seed=5, n_offset=n_off, Nt_global=Nt_global)
+    # copy this rank's slice of the parameters
+    full = CosmosEngine(d, K=K, device="cpu", lib=hc, seed=5)
+    oracle_to_engine(o, full)
+    fv, sv = full.named("params"), eng.named("params")
+    lo, hi = n_off, n_off + sub.images.shape[0]
+    for n in sv:
+        if sv[n].dim() == 4:
+            sv[n].copy_(fv[n][:, lo:hi])
+        elif sv[n].dim() == 3:
+            sv[n].copy_(fv[n][lo:hi])
+        else:
+            sv[n].copy_(fv[n])
+    allreduce = make_allreduce()
+    for _ in range(2):
+        eng.step(allreduce=allreduce)
+    out = {"rank": rank, "lo": lo, "hi": hi, "elbo": float(eng.elbo_out[0]),
+           "params": {n: v.clone().numpy() for n, v in eng.named("params").items()}}
+    if rank == 0:
+        for _ in range(2):
+            full.step()
+        out["full_elbo"] = float(full.elbo_out[0])
+        out["full_params"] = {n: v.clone().numpy() for n, v in full.named("params").items()}
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_steps_equal_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = outs[0]
+    # the ELBO every rank reports is the global one and equals the single-process value
+    for o in outs:
+        assert abs(o["elbo"] - ref["full_elbo"]) <= 1e-6 * abs(ref["full_elbo"])
+    for o in outs:
+        lo, hi = o["lo"], o["hi"]
+        for n, v in o["params"].items():
+            fp = ref["full_params"][n]
+            want = fp[:, lo:hi] if v.ndim == 4 else (fp[lo:hi] if v.ndim == 3 else fp)
+            assert abs(v - want).max() <= 2e-6, n
+
+
+def test_shard_bounds_cover_everything():
+    from tapqir_amd.parallel import shard_bounds
+
+    for Nt in (1, 7, 400, 3200):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(Nt, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == Nt
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
