@@ -119,6 +119,8 @@ typedef struct {
   float* exp_avg_sq;
   /* workspace (device) */
   float* lat;                  /* [1+4K][B]        latent draws: b, h[K], w[K], x[K], y[K] */
+  float* site;                 /* [6][(1+4K)*B]    per-site guide terms (log q, its derivatives, implicit
+                                                   reparameterisation gradients), same site order as lat */
   float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K] */
   float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */
   float* blk_part;             /* [nblk][3+3Q]     per-workgroup partial sums */
@@ -131,6 +133,7 @@ typedef struct {
   int32_t nb, fb;
   int32_t n_offset;            /* global index of local AOI 0 (AOI sharding: RNG streams use global ids) */
   int32_t draw_globals;        /* 1: draw the global base variates; 0: use the contents of gbase */
+  int32_t draw_locals;         /* 1: draw b, h, w, x, y; 0: use the contents of lat (parity tests) */
   float scale_n;               /* Nt_global / nb_global */
   float scale;                 /* scale_n * F / fb */
   float global_weight;         /* weight of the global ELBO part on this rank (1 on exactly one rank for reporting) */
@@ -152,8 +155,11 @@ int64_t tq_gbase_size(void);
 int64_t tq_cosmos_nblk(int64_t B);              /* rows of blk_part */
 int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K);
 
-/* guide draws: globals (gain, pi, lamda, proximity) + derived tables, then b, h, w, x, y per unit
- * (cosmos.py:342-368, 408-462; torch Gamma/Beta rsample + pyro AffineBeta clamp) */
+/* guide draws: globals (gain, pi, lamda, proximity) + derived tables; then, one lane per
+ * (unit, site), b, h, w, x, y (cosmos.py:342-368, 408-462; torch Gamma/Beta rsample + pyro
+ * AffineBeta clamp) together with log q of the draw, its derivatives and the implicit
+ * reparameterisation gradient of the draw -- everything about a guide site that depends on that
+ * site alone */
 int tq_cosmos_sample_globals(const tq_cosmos_args* a, void* stream);
 int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream);
 /* likelihood + all per-unit / per-AOI ELBO terms and gradients; fills grad (local + AOI parts) and gsum */

@@ -45,10 +45,11 @@ class CosmosArgs(C.Structure):
         ("images", C.c_void_p), ("xy", C.c_void_p), ("is_ontarget", C.c_void_p), ("aoi_mask", C.c_void_p),
         ("ndx", C.c_void_p), ("fdx", C.c_void_p), ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
         ("params", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-        ("lat", C.c_void_p), ("pix", C.c_void_p), ("aoi_part", C.c_void_p), ("blk_part", C.c_void_p),
+        ("lat", C.c_void_p), ("site", C.c_void_p), ("pix", C.c_void_p), ("aoi_part", C.c_void_p), ("blk_part", C.c_void_p),
         ("gsum", C.c_void_p), ("globals", C.c_void_p), ("gbase", C.c_void_p), ("elbo_out", C.c_void_p),
         ("Nt", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
         ("nb", C.c_int32), ("fb", C.c_int32), ("n_offset", C.c_int32), ("draw_globals", C.c_int32),
+        ("draw_locals", C.c_int32),
         ("scale_n", C.c_float), ("scale", C.c_float), ("global_weight", C.c_float),
         ("eps", C.c_float),
         ("width_min", C.c_float), ("width_max", C.c_float), ("height_std", C.c_float),

@@ -35,20 +35,22 @@ TQ_HD TqGlobalConsts tq_global_consts(const tq_cosmos_args& a) {
   return c;
 }
 
-// ---- global sites: draw + tables (one work item) ------------------------------------------------------
-TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a) {
+// ---- global sites: draw + tables, one work item per site s in [0, 2+2Q) ---------------------------------
+TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
   const TqGlobalConsts C = tq_global_consts(a);
   TqGlobalParams p;
   tq_globals_constrain(a.params + tq_global_base(a), C, &p);
-  TqGlobalBase* gb = (TqGlobalBase*)a.gbase;
-  if (a.draw_globals) tq_globals_draw(p, C, a.seed, a.step, gb);
-  tq_globals_tables(p, *gb, C, (TqGlobals*)a.globals);
+  tq_globals_sample_site(s, p, C, a.seed, a.step, a.draw_globals, (TqGlobalBase*)a.gbase, (TqGlobals*)a.globals);
 }
 
-// ---- local guide draws: work item t = site * B + i, site in [0, 1+4K): b, h[k], w[k], x[k], y[k] ---------
-TQ_HD void tq_body_sample_local(const tq_cosmos_args& a, int64_t t) {
+// ---- local guide sites: work item t = site * B + i, site in [0, 1+4K): b, h[k], w[k], x[k], y[k] ---------
+// Draws the latent (or takes it from `lat` when draw_locals == 0) and evaluates the site's guide
+// terms (tq_site.h: TQ_NSITE_TERMS per site).  Lanes of a wave share the site kind (site-major
+// order), so the Gamma and Beta code paths do not diverge inside a wave.
+TQ_HD void tq_body_site(const tq_cosmos_args& a, int64_t t) {
   const int K = a.K;
   const int64_t B = tq_batch_units(a), U = tq_num_units(a);
+  const int64_t NS = (int64_t)(1 + 4 * K) * B;
   const int site = (int)(t / B);
   const int64_t i = t % B;
   const TqUnitIdx ix = tq_decode_unit(a, i);
@@ -57,13 +59,15 @@ TQ_HD void tq_body_sample_local(const tq_cosmos_args& a, int64_t t) {
   TqPhilox s;
   tq_philox_init(&s, a.seed, a.step, (uint32_t)site, elem);
   const float tiny = 1.17549435e-38f;
-  float val;
-  if (site == 0 || site <= K) {  // Gamma(loc*beta, beta): background or height
+  float val = a.lat[t];
+  float terms[TQ_NSITE_TERMS];
+  if (site <= K) {  // Gamma(loc*beta, beta): background (site 0) or height
     const int rl = site == 0 ? TQ_ROW_BLOC(K) : TQ_ROW(TQ_P_HLOC, site - 1, K);
     const int rb = site == 0 ? TQ_ROW_BBETA(K) : TQ_ROW(TQ_P_HBETA, site - 1, K);
     const float ul = P[rl * U + ix.u], ub = P[rb * U + ix.u];
-    const float alpha = expf(ul + ub), beta = expf(ub);
-    val = fmaxf(tq_sample_std_gamma(&s, alpha) / beta, tiny);
+    const float loc = expf(ul), beta = expf(ub);
+    if (a.draw_locals) val = fmaxf(tq_sample_std_gamma(&s, loc * beta) / beta, tiny);
+    tq_gamma_site_terms(val, loc, beta, terms);
   } else {  // AffineBeta
     const int j = site - 1 - K;
     const int kind = j / K, k = j % K;  // 0: width, 1: x, 2: y
@@ -81,13 +85,18 @@ TQ_HD void tq_body_sample_local(const tq_cosmos_args& a, int64_t t) {
     const float sc = hi - lo;
     const float mean = (lo + a.eps) + (sc - 2.0f * a.eps) * tq_sigmoid(um);
     const float size = 2.0f + expf(us);
-    const float c1 = size * (mean - lo) / sc, c0 = size * (hi - mean) / sc;
-    const float g1 = tq_sample_std_gamma(&s, c1), g0 = tq_sample_std_gamma(&s, c0);
-    float tt = g1 / (g1 + g0);
-    tt = fminf(fmaxf(tt, tiny), 1.0f - 5.96046448e-08f);  // torch._sample_dirichlet clamp
-    val = fminf(fmaxf(lo + sc * tt, lo + a.eps * sc), hi - a.eps * sc);  // pyro AffineBeta.rsample clamp
+    if (a.draw_locals) {
+      const float c1 = size * (mean - lo) / sc, c0 = size * (hi - mean) / sc;
+      const float g1 = tq_sample_std_gamma(&s, c1), g0 = tq_sample_std_gamma(&s, c0);
+      float tt = g1 / (g1 + g0);
+      tt = fminf(fmaxf(tt, tiny), 1.0f - 5.96046448e-08f);  // torch._sample_dirichlet clamp
+      val = fminf(fmaxf(lo + sc * tt, lo + a.eps * sc), hi - a.eps * sc);  // pyro AffineBeta.rsample clamp
+    }
+    tq_affine_beta_site_terms(val, mean, size, lo, hi, a.eps, terms);
   }
-  a.lat[(int64_t)site * B + i] = val;
+  a.lat[t] = val;
+#pragma unroll
+  for (int j = 0; j < TQ_NSITE_TERMS; ++j) a.site[(int64_t)j * NS + t] = terms[j];
 }
 
 // ---- per-unit ELBO terms and gradients --------------------------------------------------------------------
@@ -132,6 +141,19 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
     in.gx[k] = a.pix[(int64_t)(M + 2 + 2 * K + k) * B + i];
     in.gy[k] = a.pix[(int64_t)(M + 2 + 3 * K + k) * B + i];
   }
+  const int64_t NS = (int64_t)(1 + 4 * K) * B;
+#pragma unroll
+  for (int j = 0; j < TQ_NSITE_TERMS; ++j) {
+    const float* sj = a.site + (int64_t)j * NS;
+    in.sb[j] = sj[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      in.sh[k][j] = sj[(int64_t)(1 + k) * B + i];
+      in.sw[k][j] = sj[(int64_t)(1 + K + k) * B + i];
+      in.sx[k][j] = sj[(int64_t)(1 + 2 * K + k) * B + i];
+      in.sy[k][j] = sj[(int64_t)(1 + 3 * K + k) * B + i];
+    }
+  }
   const bool masked = a.aoi_mask && !a.aoi_mask[ix.n];
   in.wu = masked ? 0.0f : a.scale;
   in.on = a.is_ontarget[ix.n] ? 1 : 0;
@@ -171,17 +193,28 @@ TQ_HD void tq_body_aoi_finish(const tq_cosmos_args& a, int ai, int c, float sum_
   *elbo = e;
 }
 
-// ---- global sites: gradient (one work item) ---------------------------------------------------------------
-TQ_HD void tq_body_globals_grad(const tq_cosmos_args& a) {
+// ---- global sites: gradient of site s; returns the site's part of the ELBO ---------------------------------
+TQ_HD double tq_body_globals_grad(const tq_cosmos_args& a, int s) {
   const TqGlobalConsts C = tq_global_consts(a);
   const float* u = a.params + tq_global_base(a);
   TqGlobalParams p;
   tq_globals_constrain(u, C, &p);
   double g_u[TQ_NGLOBAL(TQ_MAXQ)];
-  const double eg = tq_globals_grad(u, p, *(const TqGlobalBase*)a.gbase, *(const TqGlobals*)a.globals, C, a.gsum, g_u);
+  for (int j = 0; j < TQ_NGLOBAL(TQ_MAXQ); ++j) g_u[j] = 0.0;
+  const double eg = tq_globals_grad_site(s, p, *(const TqGlobalBase*)a.gbase, *(const TqGlobals*)a.globals, C, a.gsum, g_u);
   float* g = a.grad + tq_global_base(a);
-  for (int j = 0; j < TQ_NGLOBAL(a.C); ++j) g[j] = (float)g_u[j];
-  a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
+  const int Q = a.C;
+  // each site owns its entries of the global gradient vector
+  if (s == 0) { g[0] = (float)g_u[0]; g[1] = (float)g_u[1]; }
+  else if (s == 1) { g[2] = (float)g_u[2]; g[3] = (float)g_u[3]; }
+  else if (s < 2 + Q) { const int q = s - 2; g[4 + q] = (float)g_u[4 + q]; g[4 + Q + q] = (float)g_u[4 + Q + q]; }
+  else {
+    const int q = s - 2 - Q;
+    g[4 + 2 * Q + 2 * q] = (float)g_u[4 + 2 * Q + 2 * q];
+    g[4 + 2 * Q + 2 * q + 1] = (float)g_u[4 + 2 * Q + 2 * q + 1];
+    g[4 + 4 * Q + q] = (float)g_u[4 + 4 * Q + q];
+  }
+  return eg;
 }
 
 // ---- Adam on one element (torch.optim.Adam, no amsgrad / weight decay; minimises -ELBO) ------------------

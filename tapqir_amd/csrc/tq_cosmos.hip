@@ -23,13 +23,15 @@ __device__ __forceinline__ float tq_wave_sum(float v) {
 }
 
 // ---- sampling ------------------------------------------------------------------------------------------
+// one wave per global site (4 independent instruction streams instead of one serial lane)
 __global__ void tq_sample_globals_kernel(const tq_cosmos_args a) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) tq_body_sample_globals(a);
+  const int s = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0 && s < TQ_NGSITES(a.C)) tq_body_sample_globals(a, s);
 }
 
 __global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t total) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < total) tq_body_sample_local(a, t);
+  if (t < total) tq_body_site(a, t);
 }
 
 // ---- per-unit terms ------------------------------------------------------------------------------------
@@ -104,7 +106,15 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const tq_cosmos_args a, 
 }
 
 __global__ void tq_globals_grad_kernel(const tq_cosmos_args a) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) tq_body_globals_grad(a);
+  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+  const int s = threadIdx.x >> 6, ns = TQ_NGSITES(a.C);
+  if ((threadIdx.x & 63) == 0 && s < ns) s_e[s] = tq_body_globals_grad(a, s);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double eg = 0.0;
+    for (int j = 0; j < ns; ++j) eg += s_e[j];
+    a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
+  }
 }
 
 __global__ __launch_bounds__(256) void tq_adam_kernel(const tq_cosmos_args a, const int64_t total) {
@@ -147,14 +157,14 @@ extern "C" int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32
 
 extern "C" int tq_cosmos_sample_globals(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "sample_globals")) return rc;
-  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(1), dim3(64 * TQ_NGSITES(a->C)), 0, (hipStream_t)stream, *a);
   return check_launch("tq_sample_globals_kernel");
 }
 
 extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "sample_locals")) return rc;
-  if (!a->lat) {
-    tq_set_error("tq_cosmos_sample_locals: lat is NULL");
+  if (!a->lat || !a->site) {
+    tq_set_error("tq_cosmos_sample_locals: lat or site is NULL");
     return TQ_ERR_ARG;
   }
   const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
@@ -166,7 +176,7 @@ extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
 extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "elbo_grads")) return rc;
   if (!a->images || !a->xy || !a->is_ontarget || !a->offset_samples || !a->offset_logits || !a->grad || !a->lat ||
-      !a->pix || !a->aoi_part || !a->blk_part || !a->gsum) {
+      !a->site || !a->pix || !a->aoi_part || !a->blk_part || !a->gsum) {
     tq_set_error("tq_cosmos_elbo_grads: NULL required pointer");
     return TQ_ERR_ARG;
   }
@@ -222,7 +232,7 @@ extern "C" int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream) {
     tq_set_error("tq_cosmos_globals_grad: NULL required pointer");
     return TQ_ERR_ARG;
   }
-  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(1), dim3(64 * TQ_NGSITES(a->C)), 0, (hipStream_t)stream, *a);
   return check_launch("tq_globals_grad_kernel");
 }
 

@@ -80,55 +80,61 @@ TQ_HD void tq_globals_constrain(const float* u, const TqGlobalConsts& C, TqGloba
   }
 }
 
-// Draw the base variates of the global guide sites (cosmos.py:342-368).
-TQ_HD void tq_globals_draw(const TqGlobalParams& p, const TqGlobalConsts& C, uint64_t seed, uint32_t step,
-                           TqGlobalBase* b) {
-  TqPhilox s;
-  tq_philox_init(&s, seed, step, /*site=*/0xFFF, /*elem=*/0);
-  b->gain_g = tq_sample_std_gamma(&s, (float)(p.gain_loc * p.gain_beta));
-  {
-    const double c1 = p.prox_size * p.prox_loc / ((C.P + 1) / sqrt(12.0));
-    const double c0 = p.prox_size - c1;
-    const double g1 = tq_sample_std_gamma(&s, (float)c1), g0 = tq_sample_std_gamma(&s, (float)c0);
-    b->prox_t = g1 / (g1 + g0);
-  }
-  for (int q = 0; q < C.Q; ++q) {
-    b->lamda_g[q] = tq_sample_std_gamma(&s, (float)(p.lamda_loc[q] * p.lamda_beta[q]));
-    const double g0 = tq_sample_std_gamma(&s, (float)(p.pi_mean[q][0] * p.pi_size[q]));
-    const double g1 = tq_sample_std_gamma(&s, (float)(p.pi_mean[q][1] * p.pi_size[q]));
-    b->pi_x[q][0] = g0 / (g0 + g1);
-    b->pi_x[q][1] = g1 / (g0 + g1);
-  }
-}
+// Global guide sites are numbered s = 0: gain, 1: proximity, 2+q: lamda_q, 2+Q+q: pi_q.  Each site
+// has its own Philox stream, draws its own base variates and fills its own fields of TqGlobals, so
+// the device runs one site per wave (tq_cosmos.hip) and the host loops over s.
+#define TQ_NGSITES(Q) (2 + 2 * (Q))
 
 TQ_HD double tq_clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// Latents + derived tables from the base draws.
-TQ_HD void tq_globals_tables(const TqGlobalParams& p, const TqGlobalBase& b, const TqGlobalConsts& C, TqGlobals* G) {
+// Draw (if `draw`) the base variates of site s (cosmos.py:342-368) and derive its latents/tables.
+TQ_HD void tq_globals_sample_site(int s, const TqGlobalParams& p, const TqGlobalConsts& C, uint64_t seed, uint32_t step,
+                                  int draw, TqGlobalBase* b, TqGlobals* G) {
   const double Hs = (C.P + 1) / sqrt(12.0), H = (C.P + 1) / 2.0;
   const double tiny = 1.1754943508222875e-38;
-  double gain = b.gain_g / p.gain_beta;
-  if (gain < tiny) gain = tiny;
-  const double sigma = tq_clampd(Hs * b.prox_t, C.eps * Hs, Hs - C.eps * Hs);
-  const double cs = 0.5 * ((H / sigma) * (H / sigma) - 1.0);
-  double lg1, dg1, lg2, dg2;
-  tq_lgamma_digamma_d(cs, &lg1, &dg1);
-  tq_lgamma_digamma_d(2.0 * cs, &lg2, &dg2);
-  G->gain = (float)gain;
-  G->proximity = (float)sigma;
-  G->cs = (float)cs;
-  G->lnB_s = (float)(2.0 * lg1 - lg2 + 2.0 * (cs - 1.0) * 0.69314718055994530942);
-  G->dlnB_s = (float)(2.0 * dg1 - 2.0 * dg2 + 2.0 * 0.69314718055994530942);
-  for (int q = 0; q < C.Q; ++q) {
-    double lam = b.lamda_g[q] / p.lamda_beta[q];
+  const int Q = C.Q;
+  TqPhilox ph;
+  tq_philox_init(&ph, seed, step, /*site=*/0xFFF, /*elem=*/(uint64_t)s);
+  if (s == 0) {
+    if (draw) b->gain_g = tq_sample_std_gamma(&ph, (float)(p.gain_loc * p.gain_beta));
+    double gain = b->gain_g / p.gain_beta;
+    if (gain < tiny) gain = tiny;
+    G->gain = (float)gain;
+  } else if (s == 1) {
+    if (draw) {
+      const double c1 = p.prox_size * p.prox_loc / Hs, c0 = p.prox_size - c1;
+      const double g1 = tq_sample_std_gamma(&ph, (float)c1), g0 = tq_sample_std_gamma(&ph, (float)c0);
+      b->prox_t = g1 / (g1 + g0);
+    }
+    const double sigma = tq_clampd(Hs * b->prox_t, C.eps * Hs, Hs - C.eps * Hs);
+    const double cs = 0.5 * ((H / sigma) * (H / sigma) - 1.0);
+    double lg1, dg1, lg2, dg2;
+    tq_lgamma_digamma_d(cs, &lg1, &dg1);
+    tq_lgamma_digamma_d(2.0 * cs, &lg2, &dg2);
+    G->proximity = (float)sigma;
+    G->cs = (float)cs;
+    G->lnB_s = (float)(2.0 * lg1 - lg2 + 2.0 * (cs - 1.0) * 0.69314718055994530942);
+    G->dlnB_s = (float)(2.0 * dg1 - 2.0 * dg2 + 2.0 * 0.69314718055994530942);
+  } else if (s < 2 + Q) {
+    const int q = s - 2;
+    if (draw) b->lamda_g[q] = tq_sample_std_gamma(&ph, (float)(p.lamda_loc[q] * p.lamda_beta[q]));
+    double lam = b->lamda_g[q] / p.lamda_beta[q];
     if (lam < tiny) lam = tiny;
     double a, da, c = 0.5, dc = 0.0;
     tq_mean_frac(lam, C.K, &a, &da);
     if (C.K > 1) tq_mean_frac(lam, C.K - 1, &c, &dc);
     G->lamda[q] = (float)lam;
-    G->rho[q] = (float)b.pi_x[q][1];
     G->a[q] = (float)a;
     G->c[q] = (float)c;
+  } else {
+    const int q = s - 2 - Q;
+    if (draw) {
+      const double g0 = tq_sample_std_gamma(&ph, (float)(p.pi_mean[q][0] * p.pi_size[q]));
+      const double g1 = tq_sample_std_gamma(&ph, (float)(p.pi_mean[q][1] * p.pi_size[q]));
+      b->pi_x[q][0] = g0 / (g0 + g1);
+      b->pi_x[q][1] = g1 / (g0 + g1);
+    }
+    G->rho[q] = (float)b->pi_x[q][1];
   }
 }
 
@@ -156,25 +162,22 @@ TQ_HD double tq_gamma_site_d(double v, double g_base, double loc, double beta, d
   return lq;
 }
 
-// Gradient of the ELBO w.r.t. the unconstrained global parameters, given the cross-unit sums
+// Gradient of the ELBO w.r.t. the unconstrained parameters of global site s, given the cross-unit sums
 //   gsum[TQ_GS_GAIN] = d/d gain, gsum[TQ_GS_CS] = d/d cs, gsum[TQ_GS_Q0+3q..] = d/d (rho_q, a_q, c_q)
-// of the local part.  Returns the global part of the ELBO (model - guide log-densities of the
-// four global sites).
-TQ_HD double tq_globals_grad(const float* u, const TqGlobalParams& p, const TqGlobalBase& b, const TqGlobals& G,
-                             const TqGlobalConsts& C, const double* gsum, double* g_u) {
+// of the local part.  Writes the site's entries of g_u and returns the site's part of the ELBO
+// (model - guide log-density).
+TQ_HD double tq_globals_grad_site(int s, const TqGlobalParams& p, const TqGlobalBase& b, const TqGlobals& G,
+                                  const TqGlobalConsts& C, const double* gsum, double* g_u) {
   const int Q = C.Q;
   const double Hs = (C.P + 1) / sqrt(12.0), H = (C.P + 1) / 2.0;
-  double elbo = 0.0;
-  // ---- gain: prior HalfNormal(gain_std) ----
-  {
-    const double g = G.gain, s = C.gain_std;
-    const double lp = log(2.0) - log(s) - 0.91893853320467274178 - g * g / (2 * s * s);
-    const double e = gsum[TQ_GS_GAIN] - g / (s * s);
+  if (s == 0) {  // ---- gain: prior HalfNormal(gain_std) ----
+    const double g = G.gain, sd = C.gain_std;
+    const double lp = log(2.0) - log(sd) - 0.91893853320467274178 - g * g / (2 * sd * sd);
+    const double e = gsum[TQ_GS_GAIN] - g / (sd * sd);
     const double lq = tq_gamma_site_d(g, b.gain_g, p.gain_loc, p.gain_beta, e, &g_u[0], &g_u[1]);
-    elbo += lp - lq;
+    return lp - lq;
   }
-  // ---- proximity: prior Exponential(rate); guide AffineBeta(loc, size, 0, Hs) ----
-  {
+  if (s == 1) {  // ---- proximity: prior Exponential(rate); guide AffineBeta(loc, size, 0, Hs) ----
     const double sg = G.proximity, rate = C.proximity_rate;
     const double lp = log(rate) - rate * sg;
     const double dcs_dsigma = -H * H / (sg * sg * sg);
@@ -188,57 +191,57 @@ TQ_HD double tq_globals_grad(const float* u, const TqGlobalParams& p, const TqGl
     const double dlq_dsg = ((c1 - 1) / t - (c0 - 1) / (1 - t)) / Hs;
     const double e = gsum[TQ_GS_CS] * dcs_dsigma - rate - dlq_dsg;
     const bool clamped = (sg <= C.eps * Hs) || (sg >= Hs - C.eps * Hs);
-    double dy1 = 0, dy0 = 0;
-    if (!clamped) {
-      dy1 = Hs * (double)tq_dirichlet_grad((float)b.prox_t, (float)c1, (float)size) * (1 - b.prox_t);
-      dy0 = -Hs * (double)tq_dirichlet_grad((float)(1 - b.prox_t), (float)c0, (float)size) * b.prox_t;
-    }
+    double dd[2];
+#pragma nounroll
+    for (int j = 0; j < 2; ++j)
+      dd[j] = clamped ? 0.0
+                      : (double)tq_dirichlet_grad((float)(j ? 1 - b.prox_t : b.prox_t), (float)(j ? c0 : c1), (float)size);
+    const double dy1 = Hs * dd[0] * (1 - b.prox_t), dy0 = -Hs * dd[1] * b.prox_t;
     const double g_c1 = e * dy1 - (log(t) - dg1 + dgt);
     const double g_c0 = e * dy0 - (log1p(-t) - dg0 + dgt);
     const double d_loc = (g_c1 - g_c0) * size / Hs;
     const double d_size = g_c1 * p.prox_loc / Hs + g_c0 * (Hs - p.prox_loc) / Hs;
     g_u[2] = d_loc * (Hs - C.eps) * p.prox_sg * (1 - p.prox_sg);
     g_u[3] = d_size * p.prox_ex;
-    elbo += lp - lq;
+    return lp - lq;
   }
-  for (int q = 0; q < Q; ++q) {
-    // ---- lamda_q: prior Exponential(rate) ----
-    {
-      const double lam = G.lamda[q], rate = C.lamda_rate;
-      double a, da, c = 0.5, dc = 0.0;
-      tq_mean_frac(lam, C.K, &a, &da);
-      if (C.K > 1) tq_mean_frac(lam, C.K - 1, &c, &dc);
-      const double e = gsum[TQ_GS_Q0 + 3 * q + 1] * da + gsum[TQ_GS_Q0 + 3 * q + 2] * dc - rate;
-      const double lq = tq_gamma_site_d(lam, b.lamda_g[q], p.lamda_loc[q], p.lamda_beta[q], e, &g_u[4 + q], &g_u[4 + Q + q]);
-      elbo += log(rate) - rate * lam - lq;
-    }
-    // ---- pi_q: prior Dirichlet(1/2, 1/2); guide Dirichlet(pi_mean * pi_size) ----
-    {
-      const double x0 = b.pi_x[q][0], x1 = b.pi_x[q][1];
-      const double ps = p.pi_size[q];
-      const double c0 = p.pi_mean[q][0] * ps, c1 = p.pi_mean[q][1] * ps, tot = c0 + c1;
-      double lg0, dg0, lg1, dg1, lgt, dgt, lgh, dgh;
-      tq_lgamma_digamma_d(c0, &lg0, &dg0);
-      tq_lgamma_digamma_d(c1, &lg1, &dg1);
-      tq_lgamma_digamma_d(tot, &lgt, &dgt);
-      tq_lgamma_digamma_d(0.5, &lgh, &dgh);
-      const double lp = -2.0 * lgh - 0.5 * log(x0) - 0.5 * log(x1);  // lgamma(1) = 0
-      const double lq = lgt - lg0 - lg1 + (c0 - 1) * log(x0) + (c1 - 1) * log(x1);
-      elbo += lp - lq;
-      const double go0 = (-0.5 - (c0 - 1)) / x0;
-      const double go1 = gsum[TQ_GS_Q0 + 3 * q + 0] + (-0.5 - (c1 - 1)) / x1;
-      const double dot = x0 * go0 + x1 * go1;
-      const double dgr0 = (double)tq_dirichlet_grad((float)x0, (float)c0, (float)tot);
-      const double dgr1 = (double)tq_dirichlet_grad((float)x1, (float)c1, (float)tot);
-      const double g_c0 = dgr0 * (go0 - dot) - (dgt - dg0 + log(x0));
-      const double g_c1 = dgr1 * (go1 - dot) - (dgt - dg1 + log(x1));
-      const double d_ps = g_c0 * p.pi_mean[q][0] + g_c1 * p.pi_mean[q][1];
-      const double d_m0 = g_c0 * ps, d_m1 = g_c1 * ps;
-      const double mdot = p.pi_mean[q][0] * d_m0 + p.pi_mean[q][1] * d_m1;
-      g_u[4 + 2 * Q + 2 * q + 0] = p.pi_mean[q][0] * (d_m0 - mdot);
-      g_u[4 + 2 * Q + 2 * q + 1] = p.pi_mean[q][1] * (d_m1 - mdot);
-      g_u[4 + 4 * Q + q] = d_ps * ps;
-    }
+  if (s < 2 + Q) {  // ---- lamda_q: prior Exponential(rate) ----
+    const int q = s - 2;
+    const double lam = G.lamda[q], rate = C.lamda_rate;
+    double a, da, c = 0.5, dc = 0.0;
+    tq_mean_frac(lam, C.K, &a, &da);
+    if (C.K > 1) tq_mean_frac(lam, C.K - 1, &c, &dc);
+    const double e = gsum[TQ_GS_Q0 + 3 * q + 1] * da + gsum[TQ_GS_Q0 + 3 * q + 2] * dc - rate;
+    const double lq = tq_gamma_site_d(lam, b.lamda_g[q], p.lamda_loc[q], p.lamda_beta[q], e, &g_u[4 + q], &g_u[4 + Q + q]);
+    return log(rate) - rate * lam - lq;
   }
-  return elbo;
+  {  // ---- pi_q: prior Dirichlet(1/2, 1/2); guide Dirichlet(pi_mean * pi_size) ----
+    const int q = s - 2 - Q;
+    const double x[2] = {b.pi_x[q][0], b.pi_x[q][1]};
+    const double ps = p.pi_size[q];
+    const double c[2] = {p.pi_mean[q][0] * ps, p.pi_mean[q][1] * ps};
+    const double tot = c[0] + c[1];
+    double lg0, dg0, lg1, dg1, lgt, dgt, lgh, dgh;
+    tq_lgamma_digamma_d(c[0], &lg0, &dg0);
+    tq_lgamma_digamma_d(c[1], &lg1, &dg1);
+    tq_lgamma_digamma_d(tot, &lgt, &dgt);
+    tq_lgamma_digamma_d(0.5, &lgh, &dgh);
+    const double lp = -2.0 * lgh - 0.5 * log(x[0]) - 0.5 * log(x[1]);  // lgamma(1) = 0
+    const double lq = lgt - lg0 - lg1 + (c[0] - 1) * log(x[0]) + (c[1] - 1) * log(x[1]);
+    const double go0 = (-0.5 - (c[0] - 1)) / x[0];
+    const double go1 = gsum[TQ_GS_Q0 + 3 * q + 0] + (-0.5 - (c[1] - 1)) / x[1];
+    const double dot = x[0] * go0 + x[1] * go1;
+    double dgr[2];
+#pragma nounroll
+    for (int j = 0; j < 2; ++j) dgr[j] = (double)tq_dirichlet_grad((float)x[j], (float)c[j], (float)tot);
+    const double g_c0 = dgr[0] * (go0 - dot) - (dgt - dg0 + log(x[0]));
+    const double g_c1 = dgr[1] * (go1 - dot) - (dgt - dg1 + log(x[1]));
+    const double d_ps = g_c0 * p.pi_mean[q][0] + g_c1 * p.pi_mean[q][1];
+    const double d_m0 = g_c0 * ps, d_m1 = g_c1 * ps;
+    const double mdot = p.pi_mean[q][0] * d_m0 + p.pi_mean[q][1] * d_m1;
+    g_u[4 + 2 * Q + 2 * q + 0] = p.pi_mean[q][0] * (d_m0 - mdot);
+    g_u[4 + 2 * Q + 2 * q + 1] = p.pi_mean[q][1] * (d_m1 - mdot);
+    g_u[4 + 4 * Q + q] = d_ps * ps;
+    return lp - lq;
+  }
 }

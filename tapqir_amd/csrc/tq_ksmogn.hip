@@ -33,10 +33,118 @@ __device__ __forceinline__ float tq_group_sum16(float v) {
   return v;
 }
 
+// LDS: [16 units][tile stride] staged pixels, then [16 units][2K][P] separable Gaussian factors.
+// The tile stride is npix rounded up to 16 (mod 32) floats so that the two units sharing a
+// 32-lane ds_read_b32 group hit disjoint bank halves.
+__host__ __device__ inline int tq_tile_stride(int npix) { return ((npix + 15) / 32) * 32 + 16; }
+
+template <int K, bool ONE_OFFSET, bool BWD, bool FAST>
+__device__ __forceinline__ void tq_pixel_loop(const tq_ksmogn_args& a, const float* __restrict__ s_tile,
+                                              const float* __restrict__ s_fac, int r, int P, int npix, float b,
+                                              const float* hk, const float* amp, const float* cx, const float* cy,
+                                              float g, float rg, float ln_g, const float* W, float* ll, float& acc_b,
+                                              float& acc_g, float* S0, float* S1x, float* S1y, float* S2) {
+  constexpr int M = 1 << K;
+  const uint32_t magic = (1u << 20) / (uint32_t)P + 1u;  // exact pix / P for pix < 4096, P <= 64
+  const float off0 = a.offset_samples[0];
+  const float lw0 = a.offset_logits[0] - TQ_LN_SQRT_2PI;
+  TqCombo0 c0;
+  if (ONE_OFFSET) tq_combo0_prepare(b, rg, g, ln_g, &c0);
+
+  for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
+    const int j = (int)(((uint32_t)pix * magic) >> 20);
+    const int ic = pix - j * P;
+    const float D = s_tile[pix];
+
+    float spot[K], spotn[K], dx[K], dy[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      spotn[k] = amp[k] * s_fac[(2 * k) * TQ_MAX_P + ic] * s_fac[(2 * k + 1) * TQ_MAX_P + j];
+      spot[k] = hk[k] * spotn[k];
+      dx[k] = (float)ic - cx[k];
+      dy[k] = (float)j - cy[k];
+    }
+    float mu[M];
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) {
+      float m_ = b;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if ((mi >> k) & 1) m_ += spot[k];
+      mu[mi] = m_;
+    }
+
+    float lp[M], da[M], gq[M];
+    if (ONE_OFFSET) {
+      const float v = D - off0;
+      if (v > 0.0f) {
+        const float lv = TQ_FLOG(v);
+        const float base = lw0 - lv;
+        tq_pix_combo0(c0, v, lv, base, &lp[0], &da[0], &gq[0]);
+#pragma unroll
+        for (int mi = 1; mi < M; ++mi)
+          tq_pix_one_offset<FAST>(v, lv, base, mu[mi], rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < M; ++mi) {
+          lp[mi] = -INFINITY;
+          da[mi] = 0.0f;
+          gq[mi] = 0.0f;
+        }
+      }
+    } else {
+      TqComboPix cp[M];
+      TqLse acc[M];
+#pragma unroll
+      for (int mi = 0; mi < M; ++mi) {
+        tq_combo_prepare(mu[mi], rg, g, ln_g, &cp[mi]);
+        tq_lse_init(&acc[mi]);
+      }
+      for (int o = 0; o < a.O; ++o) {
+        const float v = D - a.offset_samples[o];
+        if (v > 0.0f) {  // ksmogn.py:226 / KeOps Step(x - g - 1): offsets at or above the pixel are excluded
+          const float lv = TQ_FLOG(v);
+          const float lwl = a.offset_logits[o] - lv;
+#pragma unroll
+          for (int mi = 0; mi < M; ++mi) tq_lse_push(&acc[mi], cp[mi], v, lv, lwl);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < M; ++mi) tq_lse_finish<FAST>(acc[mi], cp[mi], rg, &lp[mi], &da[mi], &gq[mi]);
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) ll[mi] += lp[mi];
+
+    if (BWD) {
+      float q[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) q[k] = 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < M; ++mi) {
+        const float cw = W[mi] * da[mi];
+        acc_b += cw;
+        acc_g += W[mi] * gq[mi];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if ((mi >> k) & 1) q[k] += cw;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float aq = q[k] * spotn[k];
+        S0[k] += aq;
+        S1x[k] += aq * dx[k];
+        S1y[k] += aq * dy[k];
+        S2[k] += aq * (dx[k] * dx[k] + dy[k] * dy[k]);
+      }
+    }
+  }
+}
+
 template <int K, bool ONE_OFFSET, bool BWD>
 __global__ __launch_bounds__(TQ_BLOCK) void tq_ksmogn_kernel(const tq_ksmogn_args a, const int64_t B) {
   constexpr int M = 1 << K;
-  __shared__ float s_g[TQ_UNITS_PER_BLOCK][2 * K][TQ_MAX_P];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int grp = tid >> 4;
@@ -48,6 +156,9 @@ __global__ __launch_bounds__(TQ_BLOCK) void tq_ksmogn_kernel(const tq_ksmogn_arg
   // ---- decode minibatch position -> dataset unit -------------------------------------------
   const int P = a.P;
   const int npix = P * P;
+  const int stride = tq_tile_stride(npix);
+  float* s_tile = smem + grp * stride;
+  float* s_fac = smem + TQ_UNITS_PER_BLOCK * stride + grp * (2 * K * TQ_MAX_P);
   const int c = (int)(i % a.C);
   const int64_t ab = i / a.C;
   const int bi = (int)(ab % a.fb);
@@ -55,6 +166,16 @@ __global__ __launch_bounds__(TQ_BLOCK) void tq_ksmogn_kernel(const tq_ksmogn_arg
   const int n = a.ndx ? a.ndx[ai] : ai;
   const int f = a.fdx ? a.fdx[bi] : bi;
   const int64_t u = ((int64_t)n * a.F + f) * a.C + c;
+
+  // ---- stage the P x P tile: all loads of a unit in flight at once, 16 B per lane when aligned ----
+  const float* tile = a.images + u * npix;
+  if ((npix & 3) == 0) {
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    const int n4 = npix >> 2;
+    for (int e = r; e < n4; e += TQ_LANES_PER_UNIT) *reinterpret_cast<float4*>(s_tile + 4 * e) = t4[e];
+  } else {
+    for (int e = r; e < npix; e += TQ_LANES_PER_UNIT) s_tile[e] = tile[e];
+  }
 
   const float g = a.gain[0];
   const float rg = 1.0f / g;
@@ -76,7 +197,7 @@ __global__ __launch_bounds__(TQ_BLOCK) void tq_ksmogn_kernel(const tq_ksmogn_arg
       const int axis = e >= P;
       const int p = e - axis * P;
       const float d = (float)p - (axis ? cy[k] : cx[k]);
-      s_g[grp][2 * k + axis][p] = TQ_FEXP(-d * d * inv2v);
+      s_fac[(2 * k + axis) * TQ_MAX_P + p] = TQ_FEXP(-d * d * inv2v);
     }
   }
 
@@ -115,95 +236,14 @@ __global__ __launch_bounds__(TQ_BLOCK) void tq_ksmogn_kernel(const tq_ksmogn_arg
 #pragma unroll
   for (int k = 0; k < K; ++k) S0[k] = S1x[k] = S1y[k] = S2[k] = 0.0f;
 
-  const float* tile = a.images + u * npix;
-  const uint32_t magic = (1u << 20) / (uint32_t)P + 1u;  // exact pix / P for pix < 4096, P <= 64
-  const float off0 = a.offset_samples[0];
-  const float lw0 = a.offset_logits[0];
-
-  for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
-    const int j = (int)(((uint32_t)pix * magic) >> 20);
-    const int ic = pix - j * P;
-    const float D = tile[pix];
-
-    float spotn[K], dx[K], dy[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      spotn[k] = amp[k] * s_g[grp][2 * k][ic] * s_g[grp][2 * k + 1][j];
-      dx[k] = (float)ic - cx[k];
-      dy[k] = (float)j - cy[k];
-    }
-    float mu[M];
-#pragma unroll
-    for (int mi = 0; mi < M; ++mi) {
-      float m_ = b;
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-        if ((mi >> k) & 1) m_ += hk[k] * spotn[k];
-      mu[mi] = m_;
-    }
-
-    float lp[M], da[M], gq[M];
-    if (ONE_OFFSET) {
-      const float v = D - off0;
-      if (v > 0.0f) {
-        const float lv = TQ_FLOG(v);
-#pragma unroll
-        for (int mi = 0; mi < M; ++mi) tq_pix_one_offset(v, lv, lw0, mu[mi], rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < M; ++mi) {
-          lp[mi] = -INFINITY;
-          da[mi] = 0.0f;
-          gq[mi] = 0.0f;
-        }
-      }
-    } else {
-      TqComboPix cp[M];
-      TqLse acc[M];
-#pragma unroll
-      for (int mi = 0; mi < M; ++mi) {
-        tq_combo_prepare(mu[mi], rg, g, ln_g, &cp[mi]);
-        tq_lse_init(&acc[mi]);
-      }
-      for (int o = 0; o < a.O; ++o) {
-        const float v = D - a.offset_samples[o];
-        if (v > 0.0f) {  // ksmogn.py:226 / KeOps Step(x - g - 1): offsets at or above the pixel are excluded
-          const float lv = TQ_FLOG(v);
-          const float lwl = a.offset_logits[o] - lv;
-#pragma unroll
-          for (int mi = 0; mi < M; ++mi) tq_lse_push(&acc[mi], cp[mi], v, lv, lwl);
-        }
-      }
-#pragma unroll
-      for (int mi = 0; mi < M; ++mi) tq_lse_finish(acc[mi], cp[mi], rg, &lp[mi], &da[mi], &gq[mi]);
-    }
-
-#pragma unroll
-    for (int mi = 0; mi < M; ++mi) ll[mi] += lp[mi];
-
-    if (BWD) {
-      float q[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) q[k] = 0.0f;
-#pragma unroll
-      for (int mi = 0; mi < M; ++mi) {
-        const float cw = W[mi] * da[mi];
-        acc_b += cw;
-        acc_g += W[mi] * gq[mi];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          if ((mi >> k) & 1) q[k] += cw;
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float aq = q[k] * spotn[k];
-        S0[k] += aq;
-        S1x[k] += aq * dx[k];
-        S1y[k] += aq * dy[k];
-        S2[k] += aq * (dx[k] * dx[k] + dy[k] * dy[k]);
-      }
-    }
-  }
+  // alpha(m) >= background / gain for every combination and pixel: one wave-uniform test picks
+  // the branch-free loop (Binet series valid) or the general one
+  if (__all(b * rg >= 8.0f))
+    tq_pixel_loop<K, ONE_OFFSET, BWD, true>(a, s_tile, s_fac, r, P, npix, b, hk, amp, cx, cy, g, rg, ln_g, W, ll,
+                                            acc_b, acc_g, S0, S1x, S1y, S2);
+  else
+    tq_pixel_loop<K, ONE_OFFSET, BWD, false>(a, s_tile, s_fac, r, P, npix, b, hk, amp, cx, cy, g, rg, ln_g, W, ll,
+                                             acc_b, acc_g, S0, S1x, S1y, S2);
 
   // ---- reduce over the unit's 16 lanes and store ------------------------------------------------
 #pragma unroll
@@ -250,10 +290,11 @@ static int launch_k(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
   const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK)), block(TQ_BLOCK);
   const bool bwd = a.g_background != nullptr;
   const bool one = a.O == 1;
-  if (one && bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, true, true>), grid, block, 0, st, a, B);
-  else if (one) hipLaunchKernelGGL((tq_ksmogn_kernel<K, true, false>), grid, block, 0, st, a, B);
-  else if (bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, true>), grid, block, 0, st, a, B);
-  else hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, false>), grid, block, 0, st, a, B);
+  const size_t lds = sizeof(float) * TQ_UNITS_PER_BLOCK * (tq_tile_stride(a.P * a.P) + 2 * K * TQ_MAX_P);
+  if (one && bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, true, true>), grid, block, lds, st, a, B);
+  else if (one) hipLaunchKernelGGL((tq_ksmogn_kernel<K, true, false>), grid, block, lds, st, a, B);
+  else if (bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, true>), grid, block, lds, st, a, B);
+  else hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, false>), grid, block, lds, st, a, B);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     tq_set_error(hipGetErrorString(e));

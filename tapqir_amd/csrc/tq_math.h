@@ -23,15 +23,22 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define TQ_HD __host__ __device__ __forceinline__
+// The fp64 special functions below are inlined: every kernel is organised so that a lane
+// evaluates them at most twice (one guide site per lane), which keeps the code small and
+// scratch-free (device function calls would need a scratch-backed stack).
+#define TQ_HD_NOINLINE __host__ __device__ __forceinline__
 #else
 #define TQ_HD inline
+#define TQ_HD_NOINLINE inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// v_log_f32 / v_exp_f32 / v_rcp_f32: one quarter-rate instruction each on CDNA4.
-#define TQ_FLOG(x) __logf(x)
-#define TQ_FEXP(x) __expf(x)
-#define TQ_FRCP(x) __frcp_rn(x)
+// Raw v_log_f32 / v_exp_f32 / v_rcp_f32 (1 ulp, one quarter-rate instruction each on CDNA4).
+// hipcc's __logf / __frcp_rn expand to 10-12 instruction IEEE sequences (denormal scaling,
+// div_scale/div_fmas/div_fixup); every argument on the pixel path is a normal positive number.
+#define TQ_FLOG(x) (__builtin_amdgcn_logf(x) * 0.69314718055994530942f)
+#define TQ_FEXP(x) __builtin_amdgcn_exp2f((x) * 1.44269504088896340736f)
+#define TQ_FRCP(x) __builtin_amdgcn_rcpf(x)
 #else
 #define TQ_FLOG(x) logf(x)
 #define TQ_FEXP(x) expf(x)
@@ -149,6 +156,13 @@ TQ_HD void tq_binet_series(T a, T ra, T* S, T* dS) {
   *dS = r2 * (T(-1.0 / 12.0) + r2 * (T(1.0 / 120.0) + r2 * (T(-1.0 / 252.0) + r2 * T(1.0 / 240.0))));
 }
 
+// a >= 8: three terms are exact to fp32 (next terms 1/(1680 a^7) < 3e-10, 1/(240 a^8) < 3e-10)
+TQ_HD void tq_binet_fast(float ra, float* S, float* dS) {
+  const float r2 = ra * ra;
+  *S = ra * (1.0f / 12.0f + r2 * (-1.0f / 360.0f + r2 * (1.0f / 1260.0f)));
+  *dS = r2 * (-1.0f / 12.0f + r2 * (1.0f / 120.0f + r2 * (-1.0f / 252.0f)));
+}
+
 // Binet function and its derivative for any a > 0, given ln a and 1/a.
 TQ_HD void tq_binet(float a, float lna, float ra, float* S, float* dS) {
   if (a >= 8.0f) {
@@ -196,7 +210,7 @@ TQ_HD void tq_lgamma_digamma(float a, float* lg, float* dg) {
 }
 
 // double-precision versions (host-side globals math and the mid-range Beta gradient)
-TQ_HD void tq_lgamma_digamma_d(double a, double* lg, double* dg) {
+TQ_HD_NOINLINE void tq_lgamma_digamma_d(double a, double* lg, double* dg) {
   double shift_l = 0.0, shift_d = 0.0;
   while (a < 12.0) {
     shift_l += log(a);
@@ -226,7 +240,7 @@ TQ_HD float tq_sigmoid(float u) {
 // Implicit reparameterisation gradient  d g / d alpha  of g ~ Gamma(alpha, 1):
 //   -(d/dalpha CDF(g; alpha)) / pdf(g; alpha)
 // ------------------------------------------------------------------------------------------
-TQ_HD float tq_std_gamma_grad(float alpha_, float x_) {
+TQ_HD_NOINLINE float tq_std_gamma_grad(float alpha_, float x_) {
   // evaluated in double: the saddle-point branch cancels badly in float and this runs
   // once per latent scalar, not per pixel
   const double x = x_, alpha = alpha_;
@@ -258,7 +272,8 @@ TQ_HD float tq_std_gamma_grad(float alpha_, float x_) {
     }
     const double denom = sqrt(8.0 * alpha);
     const double term2 = denom / (alpha - x);
-    const double term3 = pow(x - alpha - alpha * log(x / alpha), -1.5);
+    const double t3b = x - alpha - alpha * log(x / alpha);
+    const double term3 = 1.0 / (t3b * sqrt(t3b));  // t3b^(-3/2)
     const double term23 = (x < alpha) ? term2 - term3 : term2 + term3;
     const double term1 = log(x / alpha) * term23 - sqrt(2.0 / alpha) * (alpha + x) / ((alpha - x) * (alpha - x));
     const double stirling = 1.0 + 1.0 / (12.0 * alpha) * (1.0 + 1.0 / (24.0 * alpha));
@@ -342,19 +357,63 @@ TQ_HD double tq_beta_grad_alpha_mid(double x, double alpha, double beta) {
                           (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
   const double term1_num = 2.0 * (alpha * alpha) * (x - 1.0) + alpha * beta * (x - 1.0) - x * (beta * beta);
   const double axbx = alpha * (x - 1.0) + beta * x;
-  const double term1_den = sqrt(2.0 * alpha / beta) * pow(total, 1.5) * axbx * axbx;
+  const double term1_den = sqrt(2.0 * alpha / beta) * (total * sqrt(total)) * axbx * axbx;
   const double term1 = term1_num / term1_den;
   const double term2 = 0.5 * log(alpha / (total * x));
   const double term3_num = sqrt(8.0 * alpha * beta / total);
   const double term3_den = beta * x + alpha * (x - 1.0);
   const double term3 = term3_num / term3_den;
   const double term4_base = beta * log(beta / (total * (1.0 - x))) + alpha * log(alpha / (total * x));
-  const double term4 = pow(term4_base, -1.5);
+  const double term4 = 1.0 / (term4_base * sqrt(term4_base));  // term4_base^(-3/2)
   const double term1234 = term1 + term2 * (term3 + (x < mean ? term4 : -term4));
   return stirling * prefactor * term1234;
 }
 
-TQ_HD float tq_dirichlet_grad(float x_, float alpha_, float total_) {
+// Both implicit gradients of one Beta(alpha, beta) draw x,
+//   ga = tq_dirichlet_grad(x, alpha, alpha+beta),  gb = tq_dirichlet_grad(1-x, beta, alpha+beta),
+// when both fall in the saddle-point regime: the two evaluations share total, the two logarithms
+// (each is the other's term2 and both enter term4_base), sqrt(2 alpha beta / total), term4 and the
+// Stirling ratio; |alpha (x-1) + beta x| is the same up to sign.  Returns false (nothing written) if
+// either direction needs a different branch of the piecewise scheme.
+TQ_HD bool tq_beta_grad_pair_mid(double x, double alpha, double beta, double* ga, double* gb) {
+  const double total = alpha + beta;
+  const double boundary = total * x * (1.0 - x);
+  if (!(boundary >= 2.5 && alpha > 6.0 && beta > 6.0)) return false;
+  const double mean = alpha / total;
+  const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+  if (fabs(x - mean) <= 0.1 * sd) return false;  // removable singularity: polynomial branch (cheap, rare)
+  const double y = 1.0 - x;
+  const double rt = 1.0 / total;
+  const double la = log(alpha * rt / x);  // ln(alpha / (total x))
+  const double lb = log(beta * rt / y);   // ln(beta / (total (1-x)))
+  const double base = beta * lb + alpha * la;            // total * KL(mean || x) > 0
+  const double term4 = 1.0 / (base * sqrt(base));        // base^(-3/2)
+  const double s2 = sqrt(2.0 * alpha * beta * rt);       // sqrt(2 alpha beta / total)
+  const float fa = 1.0f / (12.0f * (float)alpha), fb = 1.0f / (12.0f * (float)beta), ft = 1.0f / (12.0f * (float)total);
+  const double stirling = (double)((1.0f + fa + 0.5f * fa * fa) * (1.0f + fb + 0.5f * fb * fb) / (1.0f + ft + 0.5f * ft * ft));
+  const double axbx = beta * x - alpha * y;              // alpha (x-1) + beta x = total (x - mean)
+  const double r_ax = 1.0 / axbx;
+  const double t15 = total * sqrt(total);
+  const double sab = sqrt(alpha / beta);                 // sqrt(2 alpha / beta) = sqrt(2) sab
+  const double r_den = r_ax * r_ax / (1.41421356237309504880 * t15);
+  const double term3 = 2.0 * s2 * r_ax;                  // sqrt(8 alpha beta / total) / axbx
+  const double sgn4 = (x < mean) ? term4 : -term4;
+  // direction alpha
+  {
+    const double num = -(2.0 * alpha * alpha + alpha * beta) * y - x * beta * beta;
+    const double term1 = num * r_den / sab;
+    *ga = stirling * (-x / s2) * (term1 + 0.5 * la * (term3 + sgn4));
+  }
+  // direction beta: x -> 1-x, alpha <-> beta, axbx -> -axbx, mean -> 1-mean
+  {
+    const double num = -(2.0 * beta * beta + alpha * beta) * x - y * alpha * alpha;
+    const double term1 = num * r_den * sab;
+    *gb = stirling * (-y / s2) * (term1 + 0.5 * lb * (-term3 - sgn4));
+  }
+  return true;
+}
+
+TQ_HD_NOINLINE float tq_dirichlet_grad(float x_, float alpha_, float total_) {
   const double x = x_, alpha = alpha_, total = total_;
   const double beta = total - alpha;
   const double boundary = total * x * (1.0 - x);

@@ -32,9 +32,11 @@ TQ_HD void tq_combo_prepare(float mu, float rg, float g, float ln_g, TqComboPix*
 }
 
 // Single-offset fast path (all offset samples identical after host-side merging).
-//   v = D - delta (> 0), lv = ln v, lw = ln weight.
+//   v = D - delta (> 0), lv = ln v, base = ln w - ln v - ln sqrt(2 pi)  (shared by all combinations)
 // Outputs: lp = log-density, da = d lp / d alpha, gq = alpha (da + 1) - v / g  (gain term, see above)
-TQ_HD void tq_pix_one_offset(float v, float lv, float lw, float mu, float rg, float g, float ln_g, float* lp,
+// FAST: the caller guarantees alpha >= 8 (alpha >= background / gain for every combination).
+template <bool FAST>
+TQ_HD void tq_pix_one_offset(float v, float lv, float base, float mu, float rg, float g, float ln_g, float* lp,
                              float* da, float* gq) {
   const float rmu = TQ_FRCP(mu);
   const float rho = v * rmu;
@@ -44,11 +46,38 @@ TQ_HD void tq_pix_one_offset(float v, float lv, float lw, float mu, float rg, fl
   const float ralpha = g * rmu;
   const float lnalpha = lv - ln_g - lrho;
   float S, dS;
-  tq_binet(alpha, lnalpha, ralpha, &S, &dS);
-  *lp = lw - lv + alpha * phi + 0.5f * lnalpha - TQ_LN_SQRT_2PI - S;
-  const float d = lrho + 0.5f * ralpha - dS;
-  *da = d;
-  *gq = alpha * (phi + 0.5f * ralpha - dS);  // = alpha (d + 1 - rho)
+  if (FAST) tq_binet_fast(ralpha, &S, &dS);
+  else tq_binet(alpha, lnalpha, ralpha, &S, &dS);
+  *lp = base + alpha * phi + 0.5f * lnalpha - S;
+  const float t = 0.5f * ralpha - dS;
+  *da = lrho + t;
+  *gq = alpha * (phi + t);  // = alpha (da + 1 - rho)
+}
+
+// The all-spots-absent combination has mu = background for every pixel of a unit, so its
+// alpha-dependent terms are per-unit constants (single-offset path only).
+struct TqCombo0 {
+  float alpha, lnb, rb;  // b/g, ln b, 1/b
+  float c_lp;            // (1/2) ln alpha - S(alpha)
+  float c_da;            // 1/(2 alpha) - S'(alpha)
+};
+TQ_HD void tq_combo0_prepare(float b, float rg, float g, float ln_g, TqCombo0* c) {
+  c->alpha = b * rg;
+  c->lnb = logf(b);
+  c->rb = 1.0f / b;
+  const float lna = c->lnb - ln_g, ra = g * c->rb;
+  float S, dS;
+  tq_binet(c->alpha, lna, ra, &S, &dS);
+  c->c_lp = 0.5f * lna - S;
+  c->c_da = 0.5f * ra - dS;
+}
+TQ_HD void tq_pix_combo0(const TqCombo0& c, float v, float lv, float base, float* lp, float* da, float* gq) {
+  const float rho = v * c.rb;
+  const float lrho = lv - c.lnb;
+  const float phi = lrho + 1.0f - rho;
+  *lp = base + c.alpha * phi + c.c_lp;
+  *da = lrho + c.c_da;
+  *gq = c.alpha * (phi + c.c_da);
 }
 
 // Online log-sum-exp accumulator over offsets for one combination.
@@ -78,6 +107,7 @@ TQ_HD void tq_lse_push(TqLse* a, const TqComboPix& c, float v, float lv, float l
     a->sv += e * v;
   }
 }
+template <bool FAST>
 TQ_HD void tq_lse_finish(const TqLse& a, const TqComboPix& c, float rg, float* lp, float* da, float* gq) {
   if (a.s == 0.0f) {  // every offset masked (D <= min offset): log 0
     *lp = -INFINITY;
@@ -86,7 +116,8 @@ TQ_HD void tq_lse_finish(const TqLse& a, const TqComboPix& c, float rg, float* l
     return;
   }
   float S, dS;
-  tq_binet(c.alpha, c.lnalpha, c.ralpha, &S, &dS);
+  if (FAST) tq_binet_fast(c.ralpha, &S, &dS);
+  else tq_binet(c.alpha, c.lnalpha, c.ralpha, &S, &dS);
   const float rs = TQ_FRCP(a.s);
   *lp = a.m + TQ_FLOG(a.s) + 0.5f * c.lnalpha - TQ_LN_SQRT_2PI - S;
   const float d = a.sl * rs + 0.5f * c.ralpha - dS;

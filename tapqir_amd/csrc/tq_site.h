@@ -86,49 +86,75 @@ TQ_HD void tq_beta_logpdf(float t, float c1, float c0, float* lp, float* d_t, fl
   *d_c0 = l1t - dg0 + dgt;
 }
 
-// One AffineBeta(mean, size, low, high) guide site evaluated at the (possibly clamped) draw y.
-//   e_y   : total derivative of the objective w.r.t. y coming from everything else
-//   wq    : weight of -log q(y) in the objective (w_u * q(m_k = 1))
-// returns lq and accumulates d objective / d mean, d size (constrained parameters)
-TQ_HD float tq_affine_beta_site(float y, float mean, float size, float low, float high, float eps, float e_y,
-                                float wq, float* d_mean, float* d_size, float* d_lq_dy) {
+// ---- guide-site terms ----------------------------------------------------------------------------
+// Evaluated once per (unit, site) by the sampling kernel right after the draw (everything here
+// depends on the site's own parameters and draw only):
+//   Gamma(alpha = loc*beta, beta), draw v = g/beta:
+//     s[0] = log q(v)  s[1] = d lq/d v  s[2] = d lq/d alpha  s[3] = d lq/d beta  s[4] = d v/d alpha (implicit)
+//   AffineBeta(mean, size, low, high), draw y = low + sc*t (clamped):
+//     s[0] = log q(y)  s[1] = d lq/d y  s[2] = d lq/d c1  s[3] = d lq/d c0  s[4] = d y/d c1  s[5] = d y/d c0
+#define TQ_NSITE_TERMS 6
+
+TQ_HD void tq_gamma_site_terms(float v, float loc, float beta, float* s) {
+  float lq, d_v, d_alpha, d_beta;
+  tq_gamma_logpdf(v, loc, beta, &lq, &d_v, &d_alpha, &d_beta);
+  s[0] = lq;
+  s[1] = d_v;
+  s[2] = d_alpha;
+  s[3] = d_beta;
+  s[4] = tq_std_gamma_grad(loc * beta, v * beta) / beta;
+  s[5] = 0.0f;
+}
+
+TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low, float high, float eps, float* s) {
   const float sc = high - low;
   const float t = (y - low) / sc;
   const float c1 = size * (mean - low) / sc;
   const float c0 = size * (high - mean) / sc;
   float lq, d_t, d_c1, d_c0;
   tq_beta_logpdf(t, c1, c0, &lq, &d_t, &d_c1, &d_c0);
-  lq -= logf(sc);
-  const float dlq_dy = d_t / sc;
-  *d_lq_dy = dlq_dy;
+  s[0] = lq - logf(sc);
+  s[1] = d_t / sc;
+  s[2] = d_c1;
+  s[3] = d_c0;
   // pathwise: y = low + sc * t unless clamped by rsample
   const bool clamped = (y <= low + eps * sc) || (y >= high - eps * sc);
-  const float ey_tot = e_y - wq * dlq_dy;
-  float dy_dc1 = 0.0f, dy_dc0 = 0.0f;
+  float dd[2] = {0.0f, 0.0f};
   if (!clamped) {
-    dy_dc1 = sc * tq_dirichlet_grad(t, c1, size) * (1.0f - t);
-    dy_dc0 = -sc * tq_dirichlet_grad(1.0f - t, c0, size) * t;
+    double ga, gb;
+    if (tq_beta_grad_pair_mid((double)t, (double)c1, (double)size - (double)c1, &ga, &gb)) {
+      dd[0] = (float)ga;  // common case: both directions in the saddle-point regime, evaluated together
+      dd[1] = (float)gb;
+    } else {
+      // the two implicit gradients share one (not unrolled) loop so the fp64 code is emitted once
+#pragma nounroll
+      for (int j = 0; j < 2; ++j) dd[j] = tq_dirichlet_grad(j ? 1.0f - t : t, j ? c0 : c1, size);
+    }
   }
-  const float g_c1 = ey_tot * dy_dc1 - wq * d_c1;
-  const float g_c0 = ey_tot * dy_dc0 - wq * d_c0;
-  *d_mean = (g_c1 - g_c0) * size / sc;
-  *d_size = g_c1 * (mean - low) / sc + g_c0 * (high - mean) / sc;
-  return lq;
+  s[4] = sc * dd[0] * (1.0f - t);
+  s[5] = -sc * dd[1] * t;
 }
 
-// One Gamma(loc*beta, beta) guide site evaluated at draw v = g / beta.
-TQ_HD float tq_gamma_site(float v, float loc, float beta, float e_v, float wq, float* d_loc_u, float* d_beta_u) {
-  float lq, d_v, d_alpha, d_beta;
-  tq_gamma_logpdf(v, loc, beta, &lq, &d_v, &d_alpha, &d_beta);
+// chain rule of one Gamma site: e_v = d objective / d v from everything else, wq = weight of -log q
+TQ_HD void tq_gamma_site_chain(const float* s, float v, float loc, float beta, float e_v, float wq, float* d_loc_u,
+                               float* d_beta_u) {
   const float alpha = loc * beta;
-  const float ev_tot = e_v - wq * d_v;
-  const float dv_dalpha = tq_std_gamma_grad(alpha, v * beta) / beta;
-  const float g_alpha = ev_tot * dv_dalpha - wq * d_alpha;
-  const float g_beta_direct = ev_tot * (-v / beta) - wq * d_beta;
-  // alpha = loc*beta; loc = exp(u_loc), beta = exp(u_beta)
-  *d_loc_u = g_alpha * alpha;
-  *d_beta_u = g_alpha * alpha + g_beta_direct * beta;
-  return lq;
+  const float ev_tot = e_v - wq * s[1];
+  const float g_alpha = ev_tot * s[4] - wq * s[2];
+  const float g_beta_direct = ev_tot * (-v / beta) - wq * s[3];
+  *d_loc_u = g_alpha * alpha;                          // alpha = loc*beta; loc = exp(u_loc)
+  *d_beta_u = g_alpha * alpha + g_beta_direct * beta;  // beta = exp(u_beta)
+}
+
+// chain rule of one AffineBeta site -> d objective / d mean, d size (constrained parameters)
+TQ_HD void tq_affine_beta_site_chain(const float* s, float mean, float size, float low, float high, float e_y,
+                                     float wq, float* d_mean, float* d_size) {
+  const float sc = high - low;
+  const float ey_tot = e_y - wq * s[1];
+  const float g_c1 = ey_tot * s[4] - wq * s[2];
+  const float g_c0 = ey_tot * s[5] - wq * s[3];
+  *d_mean = (g_c1 - g_c0) * size / sc;
+  *d_size = g_c1 * (mean - low) / sc + g_c0 * (high - mean) / sc;
 }
 
 // ---- inputs / outputs of the per-unit routine ---------------------------------------------------
@@ -139,6 +165,8 @@ struct TqUnitIn {
   float b, h[K], w[K], x[K], y[K];  // latent draws
   float ll[1 << K];        // unweighted pixel log-likelihood per combination
   float gb, gh[K], gw[K], gx[K], gy[K];  // pathwise pixel gradients, already times w_u W(m)
+  float sb[TQ_NSITE_TERMS];                 // guide-site terms of b
+  float sh[K][TQ_NSITE_TERMS], sw[K][TQ_NSITE_TERMS], sx[K][TQ_NSITE_TERMS], sy[K][TQ_NSITE_TERMS];
   float wu;                // plate scale * mask
   int on;                  // is_ontarget
   int q;                   // dye / channel index
@@ -240,20 +268,20 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
     if (in.on) d_rho += w * (-r[0] / (1.0f - rho) + rsum / rho);
   }
 
-  // ---- per-spot continuous sites -----------------------------------------------------------------
+  // ---- per-spot continuous sites (densities / implicit gradients precomputed per site) -------------
   float Tk[K];
   const float w_sc = C.w_hi - C.w_lo;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float wq = wu * p1[k];
-    float lq, d_lq;
     // height: prior HalfNormal(height_std), guide Gamma(h_loc*h_beta, h_beta)
     const float hl = expf(in.u[TQ_ROW(TQ_P_HLOC, k, K)]), hb = expf(in.u[TQ_ROW(TQ_P_HBETA, k, K)]);
     const float hs = C.height_std;
     const float lp_h = TQ_LN2 - logf(hs) - TQ_LN_SQRT_2PI - in.h[k] * in.h[k] / (2.0f * hs * hs);
     const float e_h = in.gh[k] + wq * (-in.h[k] / (hs * hs));
-    lq = tq_gamma_site(in.h[k], hl, hb, e_h, wq, &out->g[TQ_ROW(TQ_P_HLOC, k, K)], &out->g[TQ_ROW(TQ_P_HBETA, k, K)]);
-    float t_k = lp_h - lq;
+    tq_gamma_site_chain(in.sh[k], in.h[k], hl, hb, e_h, wq, &out->g[TQ_ROW(TQ_P_HLOC, k, K)],
+                        &out->g[TQ_ROW(TQ_P_HBETA, k, K)]);
+    float t_k = lp_h - in.sh[k][0];
     // width: prior uniform on (w_lo, w_hi), guide AffineBeta(w_mean, w_size, w_lo, w_hi)
     {
       const float sg = tq_sigmoid(in.u[TQ_ROW(TQ_P_WMEAN, k, K)]);
@@ -261,10 +289,10 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
       const float mean = lo + (hi - lo) * sg;
       const float ex = expf(in.u[TQ_ROW(TQ_P_WSIZE, k, K)]);
       float d_mean, d_size;
-      lq = tq_affine_beta_site(in.w[k], mean, 2.0f + ex, C.w_lo, C.w_hi, eps, in.gw[k], wq, &d_mean, &d_size, &d_lq);
+      tq_affine_beta_site_chain(in.sw[k], mean, 2.0f + ex, C.w_lo, C.w_hi, in.gw[k], wq, &d_mean, &d_size);
       out->g[TQ_ROW(TQ_P_WMEAN, k, K)] = d_mean * (hi - lo) * sg * (1.0f - sg);
       out->g[TQ_ROW(TQ_P_WSIZE, k, K)] = d_size * ex;
-      t_k += -logf(w_sc) - lq;
+      t_k += -logf(w_sc) - in.sw[k][0];
     }
     // x, y: guide AffineBeta(mean, size, -H, H); model-side dependence through L(m)
     {
@@ -276,12 +304,11 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
       float d_mean, d_size_x, d_size_y;
       const float e_x = in.gx[k] + wu * dS[k] * dsx[k];
       const float e_y = in.gy[k] + wu * dS[k] * dsy[k];
-      lq = tq_affine_beta_site(in.x[k], lo + (hi - lo) * sgx, size, -H, H, eps, e_x, wq, &d_mean, &d_size_x, &d_lq);
+      tq_affine_beta_site_chain(in.sx[k], lo + (hi - lo) * sgx, size, -H, H, e_x, wq, &d_mean, &d_size_x);
       out->g[TQ_ROW(TQ_P_XMEAN, k, K)] = d_mean * (hi - lo) * sgx * (1.0f - sgx);
-      t_k -= lq;
-      lq = tq_affine_beta_site(in.y[k], lo + (hi - lo) * sgy, size, -H, H, eps, e_y, wq, &d_mean, &d_size_y, &d_lq);
+      tq_affine_beta_site_chain(in.sy[k], lo + (hi - lo) * sgy, size, -H, H, e_y, wq, &d_mean, &d_size_y);
       out->g[TQ_ROW(TQ_P_YMEAN, k, K)] = d_mean * (hi - lo) * sgy * (1.0f - sgy);
-      t_k -= lq;
+      t_k -= in.sx[k][0] + in.sy[k][0];
       out->g[TQ_ROW(TQ_P_SIZE, k, K)] = (d_size_x + d_size_y) * ex;
     }
     Tk[k] = t_k;
@@ -321,8 +348,8 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
     out->g_bsl = wu * (d_alpha * -2.0f * a0 + d_beta * -2.0f * r0);
     const float bl = expf(in.u[TQ_ROW_BLOC(K)]), bb = expf(in.u[TQ_ROW_BBETA(K)]);
     const float e_b = in.gb + wu * d_v;
-    const float lq_b = tq_gamma_site(in.b, bl, bb, e_b, wu, &out->g[TQ_ROW_BLOC(K)], &out->g[TQ_ROW_BBETA(K)]);
-    Esum += lp_b - lq_b;
+    tq_gamma_site_chain(in.sb, in.b, bl, bb, e_b, wu, &out->g[TQ_ROW_BLOC(K)], &out->g[TQ_ROW_BBETA(K)]);
+    Esum += lp_b - in.sb[0];
   }
 
   // ---- global-table partials ---------------------------------------------------------------------

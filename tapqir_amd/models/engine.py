@@ -90,13 +90,14 @@ class CosmosEngine:
         B = nb * fb * self.C
         dev, f32 = self.device, torch.float32
         self.lat = torch.zeros((1 + 4 * K) * B, dtype=f32, device=dev)
+        self.site = torch.zeros(6 * (1 + 4 * K) * B, dtype=f32, device=dev)
         self.pix = torch.zeros((M + 2 + 4 * K) * B, dtype=f32, device=dev)
         self.aoi_part = torch.zeros(3 * B, dtype=f32, device=dev)
         nblk = (B + 255) // 256
         self.blk_part = torch.zeros(nblk * (3 + 3 * self.C), dtype=f32, device=dev)
         self._ws_key = key
 
-    def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None):
+    def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None):
         nb = self.Nt if ndx is None else int(ndx.numel())
         fb = self.F if fdx is None else int(fdx.numel())
         self._workspace(nb, fb)
@@ -112,6 +113,8 @@ class CosmosEngine:
         a.offset_samples, a.offset_logits = p(self.offset_samples), p(self.offset_logits)
         a.params, a.grad, a.exp_avg, a.exp_avg_sq = p(self.params), p(self.grad), p(self.exp_avg), p(self.exp_avg_sq)
         a.lat, a.pix, a.aoi_part, a.blk_part = p(self.lat), p(self.pix), p(self.aoi_part), p(self.blk_part)
+        a.site = p(self.site)
+        a.draw_locals = int(bool(draw_globals if draw_locals is None else draw_locals))
         a.gsum, a.globals, a.gbase, a.elbo_out = p(self.gsum), p(self.globals), p(self.gbase), p(self.elbo_out)
         a.Nt, a.F, a.C, a.P, a.K, a.O = self.Nt, self.F, self.C, self.P, self.K, self.O
         a.nb, a.fb, a.n_offset, a.draw_globals = nb, fb, self.n_offset, int(bool(draw_globals))

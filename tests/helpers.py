@@ -18,6 +18,10 @@ EPS32 = float(torch.finfo(torch.float32).eps)
 
 _hc = None
 
+# stages of a step whose latent draws are supplied by the test (make_args(draw_globals=False)):
+# tables from the given global base draws, site terms of the given local draws, ELBO + gradients
+GIVEN_STAGES = ("cosmos_sample_globals", "cosmos_sample_locals", "cosmos_elbo_grads", "cosmos_globals_grad")
+
 
 def load_hostcheck():
     """g++ build of the kernels' inline math, driven on host memory (tests only)."""

@@ -23,6 +23,16 @@ void hc_std_gamma_grad(const float* alpha, const float* x, float* out, int64_t n
 void hc_dirichlet_grad(const float* x, const float* alpha, const float* total, float* out, int64_t n) {
   for (int64_t i = 0; i < n; ++i) out[i] = tq_dirichlet_grad(x[i], alpha[i], total[i]);
 }
+// both Beta implicit gradients through the fused saddle-point path (falls back to the generic one)
+void hc_beta_grad_pair(const float* x, const float* c1, const float* c0, float* ga, float* gb, uint8_t* fused, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    double a, b;
+    const float total = c1[i] + c0[i];
+    fused[i] = tq_beta_grad_pair_mid((double)x[i], (double)c1[i], (double)total - (double)c1[i], &a, &b);
+    if (fused[i]) { ga[i] = (float)a; gb[i] = (float)b; }
+    else { ga[i] = tq_dirichlet_grad(x[i], c1[i], total); gb[i] = tq_dirichlet_grad(1.0f - x[i], c0[i], total); }
+  }
+}
 void hc_sample_std_gamma(uint64_t seed, uint32_t step, uint32_t site, const float* alpha, float* out, int64_t n) {
   for (int64_t i = 0; i < n; ++i) {
     TqPhilox s;
@@ -79,6 +89,7 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
         }
       }
     }
+    const bool fast = b * rg >= 8.0f;  // device: wave-uniform __all() of the same test
     double ll[M] = {0}, acc_b = 0, acc_g = 0, S0[K] = {0}, S1x[K] = {0}, S1y[K] = {0}, S2[K] = {0};
     for (int pix = 0; pix < npix; ++pix) {
       const int j = pix / P, ic = pix % P;
@@ -96,8 +107,18 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
           if ((mi >> k) & 1) mu += hk[k] * spotn[k];
         if (a.O == 1) {
           const float v = D - a.offset_samples[0];
-          if (v > 0.0f) tq_pix_one_offset(v, logf(v), a.offset_logits[0], mu, rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
-          else { lp[mi] = -INFINITY; da[mi] = 0; gq[mi] = 0; }
+          if (v > 0.0f) {
+            const float lv = logf(v), base = a.offset_logits[0] - TQ_LN_SQRT_2PI - lv;
+            if (mi == 0) {  // the device kernel hoists the spot-free combination's per-unit constants
+              TqCombo0 c0;
+              tq_combo0_prepare(b, rg, g, ln_g, &c0);
+              tq_pix_combo0(c0, v, lv, base, &lp[mi], &da[mi], &gq[mi]);
+            } else if (fast) {
+              tq_pix_one_offset<true>(v, lv, base, mu, rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
+            } else {
+              tq_pix_one_offset<false>(v, lv, base, mu, rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
+            }
+          } else { lp[mi] = -INFINITY; da[mi] = 0; gq[mi] = 0; }
         } else {
           TqComboPix cp;
           TqLse acc;
@@ -110,7 +131,8 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
               tq_lse_push(&acc, cp, v, lv, a.offset_logits[o] - lv);
             }
           }
-          tq_lse_finish(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
+          if (fast) tq_lse_finish<true>(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
+          else tq_lse_finish<false>(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
         }
         ll[mi] += lp[mi];
       }
@@ -163,10 +185,12 @@ int hc_ksmogn_log_prob(const tq_ksmogn_args* a) {
 int64_t hc_globals_size(void) { return (int64_t)sizeof(TqGlobals); }
 int64_t hc_gbase_size(void) { return (int64_t)sizeof(TqGlobalBase); }
 
-void hc_cosmos_sample_globals(const tq_cosmos_args* a) { tq_body_sample_globals(*a); }
+void hc_cosmos_sample_globals(const tq_cosmos_args* a) {
+  for (int s = 0; s < TQ_NGSITES(a->C); ++s) tq_body_sample_globals(*a, s);
+}
 void hc_cosmos_sample_locals(const tq_cosmos_args* a) {
   const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
-  for (int64_t t = 0; t < total; ++t) tq_body_sample_local(*a, t);
+  for (int64_t t = 0; t < total; ++t) tq_body_site(*a, t);
 }
 
 }  // extern "C"
@@ -231,7 +255,11 @@ void hc_cosmos_elbo_grads(const tq_cosmos_args* a) {
   for (int j = 0; j < nq; ++j) a->gsum[j] = sums[j];
 }
 
-void hc_cosmos_globals_grad(const tq_cosmos_args* a) { tq_body_globals_grad(*a); }
+void hc_cosmos_globals_grad(const tq_cosmos_args* a) {
+  double eg = 0.0;
+  for (int s = 0; s < TQ_NGSITES(a->C); ++s) eg += tq_body_globals_grad(*a, s);
+  a->elbo_out[0] = a->gsum[TQ_GS_ELBO] + (double)a->global_weight * eg;
+}
 void hc_cosmos_adam(const tq_cosmos_args* a) {
   const int64_t total = (int64_t)TQ_NLOCAL(a->K) * tq_num_units(*a) + 2 * (int64_t)a->Nt * a->C + TQ_NGLOBAL(a->C);
   for (int64_t j = 0; j < total; ++j) tq_body_adam(*a, j);

@@ -9,7 +9,7 @@ import ctypes as C
 import pytest
 import torch
 
-from helpers import (CosmosEngine, fp32_latents, load_hostcheck, make_dataset, make_oracle, oracle_grads,
+from helpers import (GIVEN_STAGES, CosmosEngine, fp32_latents, load_hostcheck, make_dataset, make_oracle, oracle_grads,
                      oracle_to_engine, put_latents, read_engine_latents, rel_err)
 from test_hostcheck_parity import CASES
 
@@ -27,9 +27,8 @@ def run_case_gpu(dkw, K, ndx, fdx, perturb=0.3):
     elbo_o, g_o = oracle_grads(o, nd, fd, base)
     a = eng.make_args(None if ndx is None else nd, None if fdx is None else fd, draw_globals=False)
     put_latents(eng, lat32, base)
-    eng.call("cosmos_sample_globals", a)
-    eng.call("cosmos_elbo_grads", a)
-    eng.call("cosmos_globals_grad", a)
+    for stage in GIVEN_STAGES:
+        eng.call(stage, a)
     torch.cuda.synchronize()
     return o, eng, elbo_o, g_o
 
@@ -66,8 +65,8 @@ def test_device_matches_host_build_of_same_math():
         lat32, base = fp32_latents(o, nd, fd)
         a = eng.make_args(draw_globals=False)
         put_latents(eng, lat32, base)
-        for name in ("cosmos_sample_globals", "cosmos_elbo_grads", "cosmos_globals_grad"):
-            eng.call(name, a)
+        for stage in GIVEN_STAGES:
+            eng.call(stage, a)
         outs.append((eng.grad.cpu().double(), float(eng.elbo_out[0])))
     torch.cuda.synchronize()
     assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[1][1])

@@ -8,7 +8,7 @@ comparisons run through the C ABI on the GPU in test_gpu_parity.py.
 import pytest
 import torch
 
-from helpers import (CosmosEngine, fp32_latents, load_hostcheck, make_dataset, make_oracle, oracle_grads,
+from helpers import (GIVEN_STAGES, CosmosEngine, fp32_latents, load_hostcheck, make_dataset, make_oracle, oracle_grads,
                      oracle_to_engine, put_latents, rel_err)
 
 CASES = [
@@ -36,9 +36,8 @@ def run_case(dkw, K, ndx, fdx, perturb=0.3):
     elbo_o, g_o = oracle_grads(o, nd, fd, base)
     a = eng.make_args(None if ndx is None else nd, None if fdx is None else fd, draw_globals=False)
     put_latents(eng, lat32, base)
-    eng.call("cosmos_sample_globals", a)
-    eng.call("cosmos_elbo_grads", a)
-    eng.call("cosmos_globals_grad", a)
+    for stage in GIVEN_STAGES:
+        eng.call(stage, a)
     return o, eng, elbo_o, g_o
 
 

@@ -107,3 +107,25 @@ def test_mean_frac_is_probs_m_row_zero():
             ref = probs_m(t, K)[0, 0]
             (gr,) = torch.autograd.grad(ref, t)
             assert abs(v.value - float(ref)) < 1e-14 and abs(dv.value - float(gr)) < 1e-13
+
+
+def test_fused_beta_gradient_pair_matches_torch():
+    """tq_beta_grad_pair_mid (both directions of one Beta draw at once) against torch._dirichlet_grad."""
+    hc = load_hostcheck()
+    g = torch.Generator().manual_seed(2)
+    n = 20000
+    c1 = 10 ** (torch.rand(n, generator=g) * 3.5 + 0.3)
+    c0 = 10 ** (torch.rand(n, generator=g) * 3.5 + 0.3)
+    x = torch.distributions.Beta(c1.double(), c0.double()).sample().clamp(1e-6, 1 - 1e-6)
+    x32, a32, b32 = _f32(x.numpy()), _f32(c1.numpy()), _f32(c0.numpy())
+    ga, gb = np.empty_like(x32), np.empty_like(x32)
+    fused = np.zeros(x32.size, dtype=np.uint8)
+    hc.hc_beta_grad_pair(_p(x32), _p(a32), _p(b32), _p(ga), _p(gb), _p(fused), C.c_int64(x32.size))
+    assert fused.mean() > 0.5  # the fused path is the common one in this regime
+    X = torch.tensor(x32, dtype=torch.float64)
+    A, B = torch.tensor(a32, dtype=torch.float64), torch.tensor(b32, dtype=torch.float64)
+    T = (torch.tensor(a32) + torch.tensor(b32)).double()  # the kernel forms total in float32
+    ref_a = torch._dirichlet_grad(X, A, T).numpy()
+    ref_b = torch._dirichlet_grad((1 - torch.tensor(x32)).double(), T - A, T).numpy()
+    assert np.all(np.abs(ga - ref_a) <= 1e-4 * np.abs(ref_a) + 1e-12)
+    assert np.all(np.abs(gb - ref_b) <= 1e-4 * np.abs(ref_b) + 1e-12)
