@@ -33,6 +33,7 @@ extern "C" {
 
 #define TQ_MAX_K 4
 #define TQ_MAX_P 32
+#define TQ_GSUM_LEN 32   /* doubles in tq_cosmos_args.gsum */
 
 int tq_version(void);
 const char* tq_last_error(void);
@@ -124,7 +125,9 @@ typedef struct {
   float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K] */
   float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */
   float* blk_part;             /* [nblk][3+3Q]     per-workgroup partial sums */
-  double* gsum;                /* [3+3Q]           cross-unit sums: d/d gain, d/d cs, ELBO, (d/d rho, a, c)[Q] */
+  double* gsum;                /* [TQ_GSUM_LEN]    cross-unit sums: d/d gain, d/d cs, ELBO, (d/d rho, a, c)[Q] in the
+                                                   first 3+3Q entries (the part a data-parallel host
+                                                   all-reduces); the tail is scratch of the library */
   void* globals;               /* TqGlobals  (tq_globals_size() bytes) */
   void* gbase;                 /* TqGlobalBase (tq_gbase_size() bytes): base draws of the global sites */
   double* elbo_out;            /* [1] ELBO of the step */

@@ -12,7 +12,8 @@ import os
 from tapqir_amd.exceptions import HipExtensionError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtapqir_hip.so")
+# TAPQIR_AMD_LIB selects another build of the same library (A/B timing of compiler flags)
+LIB_PATH = os.environ.get("TAPQIR_AMD_LIB") or os.path.join(_HERE, "libtapqir_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)

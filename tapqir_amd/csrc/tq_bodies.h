@@ -38,8 +38,8 @@ TQ_HD TqGlobalConsts tq_global_consts(const tq_cosmos_args& a) {
 // ---- global sites: draw + tables, one work item per site s in [0, 2+2Q) ---------------------------------
 TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
   const TqGlobalConsts C = tq_global_consts(a);
-  TqGlobalParams p;
-  tq_globals_constrain(a.params + tq_global_base(a), C, &p);
+  TqGlobalSite p;
+  tq_globals_constrain_site(a.params + tq_global_base(a), C, s, &p);
   tq_globals_sample_site(s, p, C, a.seed, a.step, a.draw_globals, (TqGlobalBase*)a.gbase, (TqGlobals*)a.globals);
 }
 
@@ -196,25 +196,10 @@ TQ_HD void tq_body_aoi_finish(const tq_cosmos_args& a, int ai, int c, float sum_
 // ---- global sites: gradient of site s; returns the site's part of the ELBO ---------------------------------
 TQ_HD double tq_body_globals_grad(const tq_cosmos_args& a, int s) {
   const TqGlobalConsts C = tq_global_consts(a);
-  const float* u = a.params + tq_global_base(a);
-  TqGlobalParams p;
-  tq_globals_constrain(u, C, &p);
-  double g_u[TQ_NGLOBAL(TQ_MAXQ)];
-  for (int j = 0; j < TQ_NGLOBAL(TQ_MAXQ); ++j) g_u[j] = 0.0;
-  const double eg = tq_globals_grad_site(s, p, *(const TqGlobalBase*)a.gbase, *(const TqGlobals*)a.globals, C, a.gsum, g_u);
-  float* g = a.grad + tq_global_base(a);
-  const int Q = a.C;
-  // each site owns its entries of the global gradient vector
-  if (s == 0) { g[0] = (float)g_u[0]; g[1] = (float)g_u[1]; }
-  else if (s == 1) { g[2] = (float)g_u[2]; g[3] = (float)g_u[3]; }
-  else if (s < 2 + Q) { const int q = s - 2; g[4 + q] = (float)g_u[4 + q]; g[4 + Q + q] = (float)g_u[4 + Q + q]; }
-  else {
-    const int q = s - 2 - Q;
-    g[4 + 2 * Q + 2 * q] = (float)g_u[4 + 2 * Q + 2 * q];
-    g[4 + 2 * Q + 2 * q + 1] = (float)g_u[4 + 2 * Q + 2 * q + 1];
-    g[4 + 4 * Q + q] = (float)g_u[4 + 4 * Q + q];
-  }
-  return eg;
+  TqGlobalSite p;
+  tq_globals_constrain_site(a.params + tq_global_base(a), C, s, &p);
+  return tq_globals_grad_site(s, p, *(const TqGlobalBase*)a.gbase, *(const TqGlobals*)a.globals, C, a.gsum,
+                              a.grad + tq_global_base(a));
 }
 
 // ---- Adam on one element (torch.optim.Adam, no amsgrad / weight decay; minimises -ELBO) ------------------

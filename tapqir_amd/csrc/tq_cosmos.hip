@@ -24,9 +24,8 @@ __device__ __forceinline__ float tq_wave_sum(float v) {
 
 // ---- sampling ------------------------------------------------------------------------------------------
 // one wave per global site (4 independent instruction streams instead of one serial lane)
-__global__ void tq_sample_globals_kernel(const tq_cosmos_args a) {
-  const int s = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0 && s < TQ_NGSITES(a.C)) tq_body_sample_globals(a, s);
+__global__ __launch_bounds__(64) void tq_sample_globals_kernel(const tq_cosmos_args a) {
+  if (threadIdx.x == 0) tq_body_sample_globals(a, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t total) {
@@ -105,14 +104,19 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const tq_cosmos_args a, 
   }
 }
 
-__global__ void tq_globals_grad_kernel(const tq_cosmos_args a) {
-  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
-  const int s = threadIdx.x >> 6, ns = TQ_NGSITES(a.C);
-  if ((threadIdx.x & 63) == 0 && s < ns) s_e[s] = tq_body_globals_grad(a, s);
-  __syncthreads();
+// one single-wave workgroup per global site: the fp64 special functions get the full register file
+// (no spills, hence no scratch memory: a per-lane scratch request is sized by the runtime for the
+// whole device and can push a dispatch onto the slow allocate-per-dispatch path)
+__global__ __launch_bounds__(64) void tq_globals_grad_kernel(const tq_cosmos_args a, double* site_elbo) {
+  const int s = blockIdx.x;
+  if (threadIdx.x == 0) site_elbo[s] = tq_body_globals_grad(a, s);
+}
+
+__global__ __launch_bounds__(64) void tq_elbo_finish_kernel(const tq_cosmos_args a, const double* site_elbo) {
   if (threadIdx.x == 0) {
     double eg = 0.0;
-    for (int j = 0; j < ns; ++j) eg += s_e[j];
+    const int ns = TQ_NGSITES(a.C);
+    for (int j = 0; j < ns; ++j) eg += site_elbo[j];
     a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
   }
 }
@@ -157,7 +161,7 @@ extern "C" int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32
 
 extern "C" int tq_cosmos_sample_globals(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "sample_globals")) return rc;
-  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(1), dim3(64 * TQ_NGSITES(a->C)), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(TQ_NGSITES(a->C)), dim3(64), 0, (hipStream_t)stream, *a);
   return check_launch("tq_sample_globals_kernel");
 }
 
@@ -232,8 +236,13 @@ extern "C" int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream) {
     tq_set_error("tq_cosmos_globals_grad: NULL required pointer");
     return TQ_ERR_ARG;
   }
-  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(1), dim3(64 * TQ_NGSITES(a->C)), 0, (hipStream_t)stream, *a);
-  return check_launch("tq_globals_grad_kernel");
+  // per-site ELBO parts go through the tail of the gsum buffer (gsum has 3+3Q used entries; the
+  // caller allocates TQ_GSUM_LEN doubles)
+  double* site_elbo = a->gsum + (3 + 3 * a->C);
+  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(TQ_NGSITES(a->C)), dim3(64), 0, (hipStream_t)stream, *a, site_elbo);
+  if (int rc = check_launch("tq_globals_grad_kernel")) return rc;
+  hipLaunchKernelGGL(tq_elbo_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a, (const double*)site_elbo);
+  return check_launch("tq_elbo_finish_kernel");
 }
 
 extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {

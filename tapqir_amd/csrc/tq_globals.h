@@ -53,42 +53,51 @@ TQ_HD void tq_mean_frac(double lam, int K, double* val, double* dval) {
 
 TQ_HD double tq_sigmoid_d(double u) { return u >= 0 ? 1.0 / (1.0 + exp(-u)) : exp(u) / (1.0 + exp(u)); }
 
-struct TqGlobalParams {  // constrained view of the unconstrained vector
-  double gain_loc, gain_beta, prox_loc, prox_size, prox_sg, prox_ex;
-  double lamda_loc[TQ_MAXQ], lamda_beta[TQ_MAXQ];
-  double pi_mean[TQ_MAXQ][2], pi_size[TQ_MAXQ];
+// Constrained parameters of ONE global site (scalars only: no runtime-indexed local arrays, so the
+// single-lane global kernels need no scratch memory).
+//   gain / lamda_q : loc, beta                 (Gamma(loc*beta, beta))
+//   proximity      : loc, size, sg, ex         (AffineBeta(loc, size, 0, Hs); sg = sigmoid(u), ex = exp(u))
+//   pi_q           : m0, m1, size              (Dirichlet([m0, m1] * size))
+struct TqGlobalSite {
+  double loc, beta, size, sg, ex, m0, m1;
 };
-
-TQ_HD void tq_globals_constrain(const float* u, const TqGlobalConsts& C, TqGlobalParams* p) {
-  const int Q = C.Q;
-  const double Hs = (C.P + 1) / sqrt(12.0);
-  p->gain_loc = exp((double)u[0]);
-  p->gain_beta = exp((double)u[1]);
-  p->prox_sg = tq_sigmoid_d(u[2]);
-  p->prox_loc = (Hs - C.eps) * p->prox_sg;  // interval(0, Hs - eps)
-  p->prox_ex = exp((double)u[3]);
-  p->prox_size = 2.0 + p->prox_ex;
-  for (int q = 0; q < Q; ++q) {
-    p->lamda_loc[q] = exp((double)u[4 + q]);
-    p->lamda_beta[q] = exp((double)u[4 + Q + q]);
-    const double u0 = u[4 + 2 * Q + 2 * q], u1 = u[4 + 2 * Q + 2 * q + 1];
-    const double mx = u0 > u1 ? u0 : u1;
-    const double e0 = exp(u0 - mx), e1 = exp(u1 - mx);
-    p->pi_mean[q][0] = e0 / (e0 + e1);
-    p->pi_mean[q][1] = e1 / (e0 + e1);
-    p->pi_size[q] = exp((double)u[4 + 4 * Q + q]);
-  }
-}
 
 // Global guide sites are numbered s = 0: gain, 1: proximity, 2+q: lamda_q, 2+Q+q: pi_q.  Each site
 // has its own Philox stream, draws its own base variates and fills its own fields of TqGlobals, so
 // the device runs one site per wave (tq_cosmos.hip) and the host loops over s.
 #define TQ_NGSITES(Q) (2 + 2 * (Q))
 
+TQ_HD void tq_globals_constrain_site(const float* u, const TqGlobalConsts& C, int s, TqGlobalSite* p) {
+  const int Q = C.Q;
+  const double Hs = (C.P + 1) / sqrt(12.0);
+  p->loc = p->beta = p->size = p->sg = p->ex = p->m0 = p->m1 = 0.0;
+  if (s == 0) {
+    p->loc = exp((double)u[0]);
+    p->beta = exp((double)u[1]);
+  } else if (s == 1) {
+    p->sg = tq_sigmoid_d(u[2]);
+    p->loc = (Hs - C.eps) * p->sg;  // interval(0, Hs - eps)
+    p->ex = exp((double)u[3]);
+    p->size = 2.0 + p->ex;
+  } else if (s < 2 + Q) {
+    const int q = s - 2;
+    p->loc = exp((double)u[4 + q]);
+    p->beta = exp((double)u[4 + Q + q]);
+  } else {
+    const int q = s - 2 - Q;
+    const double u0 = u[4 + 2 * Q + 2 * q], u1 = u[4 + 2 * Q + 2 * q + 1];
+    const double mx = u0 > u1 ? u0 : u1;
+    const double e0 = exp(u0 - mx), e1 = exp(u1 - mx);
+    p->m0 = e0 / (e0 + e1);
+    p->m1 = e1 / (e0 + e1);
+    p->size = exp((double)u[4 + 4 * Q + q]);
+  }
+}
+
 TQ_HD double tq_clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Draw (if `draw`) the base variates of site s (cosmos.py:342-368) and derive its latents/tables.
-TQ_HD void tq_globals_sample_site(int s, const TqGlobalParams& p, const TqGlobalConsts& C, uint64_t seed, uint32_t step,
+TQ_HD void tq_globals_sample_site(int s, const TqGlobalSite& p, const TqGlobalConsts& C, uint64_t seed, uint32_t step,
                                   int draw, TqGlobalBase* b, TqGlobals* G) {
   const double Hs = (C.P + 1) / sqrt(12.0), H = (C.P + 1) / 2.0;
   const double tiny = 1.1754943508222875e-38;
@@ -96,13 +105,13 @@ TQ_HD void tq_globals_sample_site(int s, const TqGlobalParams& p, const TqGlobal
   TqPhilox ph;
   tq_philox_init(&ph, seed, step, /*site=*/0xFFF, /*elem=*/(uint64_t)s);
   if (s == 0) {
-    if (draw) b->gain_g = tq_sample_std_gamma(&ph, (float)(p.gain_loc * p.gain_beta));
-    double gain = b->gain_g / p.gain_beta;
+    if (draw) b->gain_g = tq_sample_std_gamma(&ph, (float)(p.loc * p.beta));
+    double gain = b->gain_g / p.beta;
     if (gain < tiny) gain = tiny;
     G->gain = (float)gain;
   } else if (s == 1) {
     if (draw) {
-      const double c1 = p.prox_size * p.prox_loc / Hs, c0 = p.prox_size - c1;
+      const double c1 = p.size * p.loc / Hs, c0 = p.size - c1;
       const double g1 = tq_sample_std_gamma(&ph, (float)c1), g0 = tq_sample_std_gamma(&ph, (float)c0);
       b->prox_t = g1 / (g1 + g0);
     }
@@ -117,8 +126,8 @@ TQ_HD void tq_globals_sample_site(int s, const TqGlobalParams& p, const TqGlobal
     G->dlnB_s = (float)(2.0 * dg1 - 2.0 * dg2 + 2.0 * 0.69314718055994530942);
   } else if (s < 2 + Q) {
     const int q = s - 2;
-    if (draw) b->lamda_g[q] = tq_sample_std_gamma(&ph, (float)(p.lamda_loc[q] * p.lamda_beta[q]));
-    double lam = b->lamda_g[q] / p.lamda_beta[q];
+    if (draw) b->lamda_g[q] = tq_sample_std_gamma(&ph, (float)(p.loc * p.beta));
+    double lam = b->lamda_g[q] / p.beta;
     if (lam < tiny) lam = tiny;
     double a, da, c = 0.5, dc = 0.0;
     tq_mean_frac(lam, C.K, &a, &da);
@@ -129,8 +138,8 @@ TQ_HD void tq_globals_sample_site(int s, const TqGlobalParams& p, const TqGlobal
   } else {
     const int q = s - 2 - Q;
     if (draw) {
-      const double g0 = tq_sample_std_gamma(&ph, (float)(p.pi_mean[q][0] * p.pi_size[q]));
-      const double g1 = tq_sample_std_gamma(&ph, (float)(p.pi_mean[q][1] * p.pi_size[q]));
+      const double g0 = tq_sample_std_gamma(&ph, (float)(p.m0 * p.size));
+      const double g1 = tq_sample_std_gamma(&ph, (float)(p.m1 * p.size));
       b->pi_x[q][0] = g0 / (g0 + g1);
       b->pi_x[q][1] = g1 / (g0 + g1);
     }
@@ -164,84 +173,95 @@ TQ_HD double tq_gamma_site_d(double v, double g_base, double loc, double beta, d
 
 // Gradient of the ELBO w.r.t. the unconstrained parameters of global site s, given the cross-unit sums
 //   gsum[TQ_GS_GAIN] = d/d gain, gsum[TQ_GS_CS] = d/d cs, gsum[TQ_GS_Q0+3q..] = d/d (rho_q, a_q, c_q)
-// of the local part.  Writes the site's entries of g_u and returns the site's part of the ELBO
-// (model - guide log-density).
-TQ_HD double tq_globals_grad_site(int s, const TqGlobalParams& p, const TqGlobalBase& b, const TqGlobals& G,
-                                  const TqGlobalConsts& C, const double* gsum, double* g_u) {
+// of the local part.  Writes the site's entries of the global gradient vector `g` and returns the
+// site's part of the ELBO (model - guide log-density).
+TQ_HD double tq_globals_grad_site(int s, const TqGlobalSite& p, const TqGlobalBase& b, const TqGlobals& G,
+                                  const TqGlobalConsts& C, const double* gsum, float* g) {
   const int Q = C.Q;
   const double Hs = (C.P + 1) / sqrt(12.0), H = (C.P + 1) / 2.0;
-  if (s == 0) {  // ---- gain: prior HalfNormal(gain_std) ----
-    const double g = G.gain, sd = C.gain_std;
-    const double lp = log(2.0) - log(sd) - 0.91893853320467274178 - g * g / (2 * sd * sd);
-    const double e = gsum[TQ_GS_GAIN] - g / (sd * sd);
-    const double lq = tq_gamma_site_d(g, b.gain_g, p.gain_loc, p.gain_beta, e, &g_u[0], &g_u[1]);
+  if (s == 0 || (s >= 2 && s < 2 + Q)) {
+    // ---- Gamma sites: gain (prior HalfNormal(gain_std)) and lamda_q (prior Exponential(rate)) ----
+    double v, gb, e, lp;
+    int i_loc, i_beta;
+    if (s == 0) {
+      v = G.gain;
+      gb = b.gain_g;
+      const double sd = C.gain_std;
+      lp = log(2.0) - log(sd) - 0.91893853320467274178 - v * v / (2 * sd * sd);
+      e = gsum[TQ_GS_GAIN] - v / (sd * sd);
+      i_loc = 0; i_beta = 1;
+    } else {
+      const int q = s - 2;
+      v = G.lamda[q];
+      gb = b.lamda_g[q];
+      const double rate = C.lamda_rate;
+      double a, da, c = 0.5, dc = 0.0;
+      tq_mean_frac(v, C.K, &a, &da);
+      if (C.K > 1) tq_mean_frac(v, C.K - 1, &c, &dc);
+      lp = log(rate) - rate * v;
+      e = gsum[TQ_GS_Q0 + 3 * q + 1] * da + gsum[TQ_GS_Q0 + 3 * q + 2] * dc - rate;
+      i_loc = 4 + q; i_beta = 4 + Q + q;
+    }
+    double d_loc, d_beta;
+    const double lq = tq_gamma_site_d(v, gb, p.loc, p.beta, e, &d_loc, &d_beta);
+    g[i_loc] = (float)d_loc;
+    g[i_beta] = (float)d_beta;
     return lp - lq;
   }
-  if (s == 1) {  // ---- proximity: prior Exponential(rate); guide AffineBeta(loc, size, 0, Hs) ----
+  // ---- Beta / Dirichlet sites: proximity (AffineBeta on (0, Hs)) and pi_q (2-component Dirichlet) ----
+  double x0, c0, c1, go0, go1, lp, sc;  // x0 = first component; (c0, c1) concentrations of (x0, 1-x0)
+  if (s == 1) {
     const double sg = G.proximity, rate = C.proximity_rate;
-    const double lp = log(rate) - rate * sg;
+    lp = log(rate) - rate * sg;
+    // write the AffineBeta as a Dirichlet over (t, 1-t), t = sigma / Hs: objective derivative w.r.t. t
+    c0 = p.size * p.loc / Hs;
+    c1 = p.size - c0;
+    x0 = sg / Hs;
     const double dcs_dsigma = -H * H / (sg * sg * sg);
-    const double t = sg / Hs;
-    const double size = p.prox_size, c1 = size * p.prox_loc / Hs, c0 = size - c1;
-    double lg1, dg1, lg0, dg0, lgt, dgt;
-    tq_lgamma_digamma_d(c1, &lg1, &dg1);
-    tq_lgamma_digamma_d(c0, &lg0, &dg0);
-    tq_lgamma_digamma_d(size, &lgt, &dgt);
-    const double lq = (c1 - 1) * log(t) + (c0 - 1) * log1p(-t) + lgt - lg1 - lg0 - log(Hs);
-    const double dlq_dsg = ((c1 - 1) / t - (c0 - 1) / (1 - t)) / Hs;
-    const double e = gsum[TQ_GS_CS] * dcs_dsigma - rate - dlq_dsg;
     const bool clamped = (sg <= C.eps * Hs) || (sg >= Hs - C.eps * Hs);
-    double dd[2];
-#pragma nounroll
-    for (int j = 0; j < 2; ++j)
-      dd[j] = clamped ? 0.0
-                      : (double)tq_dirichlet_grad((float)(j ? 1 - b.prox_t : b.prox_t), (float)(j ? c0 : c1), (float)size);
-    const double dy1 = Hs * dd[0] * (1 - b.prox_t), dy0 = -Hs * dd[1] * b.prox_t;
-    const double g_c1 = e * dy1 - (log(t) - dg1 + dgt);
-    const double g_c0 = e * dy0 - (log1p(-t) - dg0 + dgt);
-    const double d_loc = (g_c1 - g_c0) * size / Hs;
-    const double d_size = g_c1 * p.prox_loc / Hs + g_c0 * (Hs - p.prox_loc) / Hs;
-    g_u[2] = d_loc * (Hs - C.eps) * p.prox_sg * (1 - p.prox_sg);
-    g_u[3] = d_size * p.prox_ex;
-    return lp - lq;
-  }
-  if (s < 2 + Q) {  // ---- lamda_q: prior Exponential(rate) ----
-    const int q = s - 2;
-    const double lam = G.lamda[q], rate = C.lamda_rate;
-    double a, da, c = 0.5, dc = 0.0;
-    tq_mean_frac(lam, C.K, &a, &da);
-    if (C.K > 1) tq_mean_frac(lam, C.K - 1, &c, &dc);
-    const double e = gsum[TQ_GS_Q0 + 3 * q + 1] * da + gsum[TQ_GS_Q0 + 3 * q + 2] * dc - rate;
-    const double lq = tq_gamma_site_d(lam, b.lamda_g[q], p.lamda_loc[q], p.lamda_beta[q], e, &g_u[4 + q], &g_u[4 + Q + q]);
-    return log(rate) - rate * lam - lq;
-  }
-  {  // ---- pi_q: prior Dirichlet(1/2, 1/2); guide Dirichlet(pi_mean * pi_size) ----
+    go0 = clamped ? 0.0 : (gsum[TQ_GS_CS] * dcs_dsigma - rate) * Hs;  // pathwise part only
+    go1 = 0.0;
+    sc = Hs;
+  } else {
     const int q = s - 2 - Q;
-    const double x[2] = {b.pi_x[q][0], b.pi_x[q][1]};
-    const double ps = p.pi_size[q];
-    const double c[2] = {p.pi_mean[q][0] * ps, p.pi_mean[q][1] * ps};
-    const double tot = c[0] + c[1];
-    double lg0, dg0, lg1, dg1, lgt, dgt, lgh, dgh;
-    tq_lgamma_digamma_d(c[0], &lg0, &dg0);
-    tq_lgamma_digamma_d(c[1], &lg1, &dg1);
-    tq_lgamma_digamma_d(tot, &lgt, &dgt);
-    tq_lgamma_digamma_d(0.5, &lgh, &dgh);
-    const double lp = -2.0 * lgh - 0.5 * log(x[0]) - 0.5 * log(x[1]);  // lgamma(1) = 0
-    const double lq = lgt - lg0 - lg1 + (c[0] - 1) * log(x[0]) + (c[1] - 1) * log(x[1]);
-    const double go0 = (-0.5 - (c[0] - 1)) / x[0];
-    const double go1 = gsum[TQ_GS_Q0 + 3 * q + 0] + (-0.5 - (c[1] - 1)) / x[1];
-    const double dot = x[0] * go0 + x[1] * go1;
-    double dgr[2];
-#pragma nounroll
-    for (int j = 0; j < 2; ++j) dgr[j] = (double)tq_dirichlet_grad((float)x[j], (float)c[j], (float)tot);
-    const double g_c0 = dgr[0] * (go0 - dot) - (dgt - dg0 + log(x[0]));
-    const double g_c1 = dgr[1] * (go1 - dot) - (dgt - dg1 + log(x[1]));
-    const double d_ps = g_c0 * p.pi_mean[q][0] + g_c1 * p.pi_mean[q][1];
-    const double d_m0 = g_c0 * ps, d_m1 = g_c1 * ps;
-    const double mdot = p.pi_mean[q][0] * d_m0 + p.pi_mean[q][1] * d_m1;
-    g_u[4 + 2 * Q + 2 * q + 0] = p.pi_mean[q][0] * (d_m0 - mdot);
-    g_u[4 + 2 * Q + 2 * q + 1] = p.pi_mean[q][1] * (d_m1 - mdot);
-    g_u[4 + 4 * Q + q] = d_ps * ps;
-    return lp - lq;
+    x0 = b.pi_x[q][0];
+    c0 = p.m0 * p.size;
+    c1 = p.m1 * p.size;
+    lp = -2.0 * 0.57236494292470008707 - 0.5 * log(x0) - 0.5 * log(1.0 - x0);  // Dirichlet(1/2,1/2): lgamma(1/2) = ln sqrt(pi)
+    go0 = -0.5 / x0;
+    go1 = gsum[TQ_GS_Q0 + 3 * q + 0] - 0.5 / b.pi_x[q][1];
+    sc = 1.0;
   }
+  const double x1 = (s == 1) ? 1.0 - x0 : b.pi_x[s - 2 - Q][1];
+  const double tot = c0 + c1;
+  double lg0, dg0, lg1, dg1, lgt, dgt;
+  tq_lgamma_digamma_d(c0, &lg0, &dg0);
+  tq_lgamma_digamma_d(c1, &lg1, &dg1);
+  tq_lgamma_digamma_d(tot, &lgt, &dgt);
+  const double lq = lgt - lg0 - lg1 + (c0 - 1) * log(x0) + (c1 - 1) * log(x1) - log(sc);
+  // total derivative of the objective w.r.t. the draw = outside part - d lq / d x
+  const double e0 = go0 - (c0 - 1) / x0, e1 = go1 - (c1 - 1) / x1;
+  const double dot = x0 * e0 + x1 * e1;
+  double dgr[2];
+#pragma nounroll
+  for (int j = 0; j < 2; ++j) dgr[j] = (double)tq_dirichlet_grad((float)(j ? x1 : x0), (float)(j ? c1 : c0), (float)tot);
+  const bool frozen = (s == 1) && (go0 == 0.0) && ((G.proximity <= C.eps * Hs) || (G.proximity >= Hs - C.eps * Hs));
+  const double g_c0 = (frozen ? 0.0 : dgr[0] * (e0 - dot)) - (dgt - dg0 + log(x0));
+  const double g_c1 = (frozen ? 0.0 : dgr[1] * (e1 - dot)) - (dgt - dg1 + log(x1));
+  if (s == 1) {
+    // c0 = size*loc/Hs, c1 = size*(Hs-loc)/Hs
+    const double d_loc = (g_c0 - g_c1) * p.size / Hs;
+    const double d_size = g_c0 * p.loc / Hs + g_c1 * (Hs - p.loc) / Hs;
+    g[2] = (float)(d_loc * (Hs - C.eps) * p.sg * (1 - p.sg));
+    g[3] = (float)(d_size * p.ex);
+  } else {
+    const int q = s - 2 - Q;
+    const double d_ps = g_c0 * p.m0 + g_c1 * p.m1;
+    const double d_m0 = g_c0 * p.size, d_m1 = g_c1 * p.size;
+    const double mdot = p.m0 * d_m0 + p.m1 * d_m1;
+    g[4 + 2 * Q + 2 * q + 0] = (float)(p.m0 * (d_m0 - mdot));
+    g[4 + 2 * Q + 2 * q + 1] = (float)(p.m1 * (d_m1 - mdot));
+    g[4 + 4 * Q + q] = (float)(d_ps * p.size);
+  }
+  return lp - lq;
 }

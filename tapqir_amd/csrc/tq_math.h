@@ -111,7 +111,12 @@ TQ_HD float tq_uniform(TqPhilox* s) {
 TQ_HD float tq_normal(TqPhilox* s) {  // Box-Muller, one value per call (the sine branch is dropped)
   const float u1 = tq_uniform(s);
   const float u2 = tq_uniform(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // v_cos_f32 takes its argument in revolutions: cos(2 pi u2) is one instruction
+  return __builtin_amdgcn_sqrtf(-2.0f * TQ_FLOG(u1)) * __builtin_amdgcn_cosf(u2);
+#else
   return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * TQ_PI * u2);
+#endif
 }
 
 // Standard Gamma(alpha, 1) draw; Marsaglia & Tsang (2000) with the alpha < 1 boost.
@@ -335,22 +340,26 @@ TQ_HD double tq_beta_grad_beta_small(double x, double alpha, double beta) {
   return (result != result) ? 0.0 : result;
 }
 
+// local polynomial of the saddle-point gradient around its removable singularity at x = mean
+TQ_HD double tq_beta_grad_window(double x, double alpha, double beta) {
+  const double total = alpha + beta;
+  const double b2 = beta * beta;
+  const double poly =
+      47.0 * x * b2 * b2 +
+      alpha * ((43.0 + 20.0 * (16.0 + 27.0 * beta) * x) * b2 * beta +
+               alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2 +
+                        alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta +
+                                 alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
+  const double prefactor_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
+  const double prefactor_den = 12960.0 * alpha * alpha * alpha * b2 * (1.0 + 12.0 * total);
+  return prefactor_num / (1.0 - x) * poly / prefactor_den;
+}
+
 TQ_HD double tq_beta_grad_alpha_mid(double x, double alpha, double beta) {
   const double total = alpha + beta;
   const double mean = alpha / total;
   const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
-  if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) {  // removable singularity at x = mean
-    const double b2 = beta * beta;
-    const double poly =
-        47.0 * x * b2 * b2 +
-        alpha * ((43.0 + 20.0 * (16.0 + 27.0 * beta) * x) * b2 * beta +
-                 alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2 +
-                          alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta +
-                                   alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
-    const double prefactor_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
-    const double prefactor_den = 12960.0 * alpha * alpha * alpha * b2 * (1.0 + 12.0 * total);
-    return prefactor_num / (1.0 - x) * poly / prefactor_den;
-  }
+  if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) return tq_beta_grad_window(x, alpha, beta);
   const double prefactor = -x / sqrt(2.0 * alpha * beta / total);
   const double stirling = (1.0 + 1.0 / (12.0 * alpha) + 1.0 / (288.0 * alpha * alpha)) *
                           (1.0 + 1.0 / (12.0 * beta) + 1.0 / (288.0 * beta * beta)) /
@@ -381,8 +390,14 @@ TQ_HD bool tq_beta_grad_pair_mid(double x, double alpha, double beta, double* ga
   if (!(boundary >= 2.5 && alpha > 6.0 && beta > 6.0)) return false;
   const double mean = alpha / total;
   const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
-  if (fabs(x - mean) <= 0.1 * sd) return false;  // removable singularity: polynomial branch (cheap, rare)
   const double y = 1.0 - x;
+  if (fabs(x - mean) <= 0.1 * sd) {
+    // removable singularity at x = mean: both directions use the local polynomial (8 % of draws;
+    // handled here so that a wave never has to run the generic piecewise code for them)
+    *ga = tq_beta_grad_window(x, alpha, beta);
+    *gb = tq_beta_grad_window(y, beta, alpha);
+    return true;
+  }
   const double rt = 1.0 / total;
   const double la = log(alpha * rt / x);  // ln(alpha / (total x))
   const double lb = log(beta * rt / y);   // ln(beta / (total (1-x)))

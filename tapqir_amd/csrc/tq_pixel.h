@@ -32,26 +32,35 @@ TQ_HD void tq_combo_prepare(float mu, float rg, float g, float ln_g, TqComboPix*
 }
 
 // Single-offset fast path (all offset samples identical after host-side merging).
-//   v = D - delta (> 0), lv = ln v, base = ln w - ln v - ln sqrt(2 pi)  (shared by all combinations)
-// Outputs: lp = log-density, da = d lp / d alpha, gq = alpha (da + 1) - v / g  (gain term, see above)
-// FAST: the caller guarantees alpha >= 8 (alpha >= background / gain for every combination).
+//   v = D - delta (> 0), lv = ln v.  The combination-independent part of the log-density,
+//   ln w - ln v - ln sqrt(2 pi), is added once per pixel by the caller; the rest is split as
+//     log p = (1/g) * [mu phi(v/mu)]  +  [ (1/2) ln alpha - S(alpha) ]
+//   so that the caller accumulates sum mu*phi and applies 1/g once per unit.
+//   Outputs: mphi = mu*phi, rest = (1/2) ln alpha - S(alpha), da = d log p / d alpha.
+// The gain term needs no per-combination work here: with one offset,
+//   alpha (da + 1) - v/g = (mu da + mu - v) / g, and the pixel sums of mu*da, mu and v are
+//   linear in sums the kernel accumulates anyway (see tq_ksmogn.hip).
+// FAST: the caller guarantees alpha >= TQ_FAST_ALPHA (alpha >= background / gain for every
+// combination); S = 1/(12a), S' = -1/(12a^2) are then exact to 7e-7 / 2e-7 absolute per pixel.
+#define TQ_FAST_ALPHA 16.0f
 template <bool FAST>
-TQ_HD void tq_pix_one_offset(float v, float lv, float base, float mu, float rg, float g, float ln_g, float* lp,
-                             float* da, float* gq) {
+TQ_HD void tq_pix_one_offset(float v, float lv_minus_lng, float mu, float rg, float g, float* mphi, float* rest,
+                             float* da) {
   const float rmu = TQ_FRCP(mu);
   const float rho = v * rmu;
   const float lrho = TQ_FLOG(rho);
-  const float phi = lrho + 1.0f - rho;
-  const float alpha = mu * rg;
+  *mphi = mu * ((lrho + 1.0f) - rho);
   const float ralpha = g * rmu;
-  const float lnalpha = lv - ln_g - lrho;
-  float S, dS;
-  if (FAST) tq_binet_fast(ralpha, &S, &dS);
-  else tq_binet(alpha, lnalpha, ralpha, &S, &dS);
-  *lp = base + alpha * phi + 0.5f * lnalpha - S;
-  const float t = 0.5f * ralpha - dS;
-  *da = lrho + t;
-  *gq = alpha * (phi + t);  // = alpha (da + 1 - rho)
+  const float lnalpha = lv_minus_lng - lrho;
+  if (FAST) {
+    *rest = 0.5f * lnalpha - ralpha * (1.0f / 12.0f);
+    *da = lrho + ralpha * (0.5f + ralpha * (1.0f / 12.0f));
+  } else {
+    float S, dS;
+    tq_binet(mu * rg, lnalpha, ralpha, &S, &dS);
+    *rest = 0.5f * lnalpha - S;
+    *da = lrho + (0.5f * ralpha - dS);
+  }
 }
 
 // The all-spots-absent combination has mu = background for every pixel of a unit, so its
@@ -63,21 +72,19 @@ struct TqCombo0 {
 };
 TQ_HD void tq_combo0_prepare(float b, float rg, float g, float ln_g, TqCombo0* c) {
   c->alpha = b * rg;
-  c->lnb = logf(b);
-  c->rb = 1.0f / b;
+  c->lnb = TQ_FLOG(b);
+  c->rb = TQ_FRCP(b);
   const float lna = c->lnb - ln_g, ra = g * c->rb;
   float S, dS;
   tq_binet(c->alpha, lna, ra, &S, &dS);
   c->c_lp = 0.5f * lna - S;
   c->c_da = 0.5f * ra - dS;
 }
-TQ_HD void tq_pix_combo0(const TqCombo0& c, float v, float lv, float base, float* lp, float* da, float* gq) {
-  const float rho = v * c.rb;
+// (per pixel only phi is needed: sum_pix [alpha phi + c_lp] = alpha * sum phi + npix * c_lp)
+TQ_HD void tq_pix_combo0(const TqCombo0& c, float v, float lv, float* phi, float* da) {
   const float lrho = lv - c.lnb;
-  const float phi = lrho + 1.0f - rho;
-  *lp = base + c.alpha * phi + c.c_lp;
+  *phi = (lrho + 1.0f) - v * c.rb;
   *da = lrho + c.c_da;
-  *gq = c.alpha * (phi + c.c_da);
 }
 
 // Online log-sum-exp accumulator over offsets for one combination.

@@ -75,7 +75,8 @@ class CosmosEngine:
         bsz = int(lib.hc_gbase_size() if self._hostcheck else lib.tq_gbase_size())
         self.globals = torch.zeros(gsz // 4, dtype=f32, device=dev)
         self.gbase = torch.zeros(bsz // 8, dtype=torch.float64, device=dev)
-        self.gsum = torch.zeros(3 + 3 * self.C, dtype=torch.float64, device=dev)
+        self._gsum_buf = torch.zeros(32, dtype=torch.float64, device=dev)  # TQ_GSUM_LEN
+        self.gsum = self._gsum_buf[: 3 + 3 * self.C]  # the part that crosses ranks
         self.elbo_out = torch.zeros(1, dtype=torch.float64, device=dev)
         self._ws_key = None
         self.adam_step = 0
@@ -115,7 +116,7 @@ class CosmosEngine:
         a.lat, a.pix, a.aoi_part, a.blk_part = p(self.lat), p(self.pix), p(self.aoi_part), p(self.blk_part)
         a.site = p(self.site)
         a.draw_locals = int(bool(draw_globals if draw_locals is None else draw_locals))
-        a.gsum, a.globals, a.gbase, a.elbo_out = p(self.gsum), p(self.globals), p(self.gbase), p(self.elbo_out)
+        a.gsum, a.globals, a.gbase, a.elbo_out = p(self._gsum_buf), p(self.globals), p(self.gbase), p(self.elbo_out)
         a.Nt, a.F, a.C, a.P, a.K, a.O = self.Nt, self.F, self.C, self.P, self.K, self.O
         a.nb, a.fb, a.n_offset, a.draw_globals = nb, fb, self.n_offset, int(bool(draw_globals))
         a.scale_n = self.Nt_global / self._nb_global(nb)

@@ -49,13 +49,15 @@ void hc_mean_frac(double lam, int K, double* val, double* dval) { tq_mean_frac(l
 
 }  // extern "C"
 
-// Host emulation of tq_ksmogn_kernel (same per-pixel functions, plain loops).
+// Host emulation of tq_ksmogn_kernel (same per-pixel functions and the same algebra for the
+// moments and the gain term; plain loops, double accumulators).
 template <int K>
 static void ksmogn_host(const tq_ksmogn_args& a) {
   constexpr int M = 1 << K;
   const int64_t B = (int64_t)a.nb * a.fb * a.C;
   const int P = a.P, npix = P * P;
   const bool bwd = a.g_background != nullptr;
+  const bool one = a.O == 1;
   const float g = a.gain[0], rg = 1.0f / g, ln_g = logf(g);
   for (int64_t i = 0; i < B; ++i) {
     const int c = (int)(i % a.C);
@@ -64,16 +66,17 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
     const int n = a.ndx ? a.ndx[ai] : ai, f = a.fdx ? a.fdx[bi] : bi;
     const int64_t u = ((int64_t)n * a.F + f) * a.C + c;
     const float tx = a.xy[2 * u], ty = a.xy[2 * u + 1], b = a.background[i];
-    float hk[K], wk[K], amp[K], cx[K], cy[K], inv2v[K];
+    float hk[K], wk[K], amph[K], cx[K], cy[K], inv2v[K];
     for (int k = 0; k < K; ++k) {
       hk[k] = a.height[k * B + i];
       wk[k] = a.width[k * B + i];
       cx[k] = a.x[k * B + i] + tx;
       cy[k] = a.y[k * B + i] + ty;
       inv2v[k] = 0.5f / (wk[k] * wk[k]);
-      amp[k] = inv2v[k] * (1.0f / TQ_PI);
+      amph[k] = hk[k] * inv2v[k] * (1.0f / TQ_PI);
     }
     float W[M];
+    for (int mi = 0; mi < M; ++mi) W[mi] = 0.0f;
     if (bwd) {
       if (a.gout) {
         for (int mi = 0; mi < M; ++mi) W[mi] = a.gout[(int64_t)mi * B + i];
@@ -89,37 +92,51 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
         }
       }
     }
-    const bool fast = b * rg >= 8.0f;  // device: wave-uniform __all() of the same test
-    double ll[M] = {0}, acc_b = 0, acc_g = 0, S0[K] = {0}, S1x[K] = {0}, S1y[K] = {0}, S2[K] = {0};
+    const bool fast = b * rg >= TQ_FAST_ALPHA;  // device: wave-uniform __all() of the same test
+    TqCombo0 c0;
+    tq_combo0_prepare(b, rg, g, ln_g, &c0);
+    double ll[M] = {0}, base = 0, acc_b = 0, acc_g = 0, sv = 0, cnt = 0;
+    double S0[K] = {0}, Sx[K] = {0}, Sy[K] = {0}, Sr[K] = {0}, SN[K] = {0};
     for (int pix = 0; pix < npix; ++pix) {
       const int j = pix / P, ic = pix % P;
       const float D = a.images[u * npix + pix];
-      float spotn[K], dx[K], dy[K];
+      const float fic = (float)ic, fj = (float)j;
+      float spot[K];
       for (int k = 0; k < K; ++k) {
-        dx[k] = (float)ic - cx[k];
-        dy[k] = (float)j - cy[k];
-        spotn[k] = amp[k] * expf(-dx[k] * dx[k] * inv2v[k]) * expf(-dy[k] * dy[k] * inv2v[k]);
+        const float dx = fic - cx[k], dy = fj - cy[k];
+        spot[k] = amph[k] * expf(-dx * dx * inv2v[k]) * expf(-dy * dy * inv2v[k]);
       }
       float lp[M], da[M], gq[M];
-      for (int mi = 0; mi < M; ++mi) {
-        float mu = b;
-        for (int k = 0; k < K; ++k)
-          if ((mi >> k) & 1) mu += hk[k] * spotn[k];
-        if (a.O == 1) {
-          const float v = D - a.offset_samples[0];
-          if (v > 0.0f) {
-            const float lv = logf(v), base = a.offset_logits[0] - TQ_LN_SQRT_2PI - lv;
-            if (mi == 0) {  // the device kernel hoists the spot-free combination's per-unit constants
-              TqCombo0 c0;
-              tq_combo0_prepare(b, rg, g, ln_g, &c0);
-              tq_pix_combo0(c0, v, lv, base, &lp[mi], &da[mi], &gq[mi]);
-            } else if (fast) {
-              tq_pix_one_offset<true>(v, lv, base, mu, rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
-            } else {
-              tq_pix_one_offset<false>(v, lv, base, mu, rg, g, ln_g, &lp[mi], &da[mi], &gq[mi]);
-            }
-          } else { lp[mi] = -INFINITY; da[mi] = 0; gq[mi] = 0; }
+      bool valid = true;
+      if (one) {
+        const float v = D - a.offset_samples[0];
+        valid = v > 0.0f;
+        if (valid) {
+          const float lv = logf(v);
+          base += (a.offset_logits[0] - TQ_LN_SQRT_2PI) - lv;
+          float phi0;
+          tq_pix_combo0(c0, v, lv, &phi0, &da[0]);
+          lp[0] = c0.alpha * phi0 + c0.c_lp;
+          for (int mi = 1; mi < M; ++mi) {
+            float mu = b, mphi, rest;
+            for (int k = 0; k < K; ++k)
+              if ((mi >> k) & 1) mu += spot[k];
+            if (fast) tq_pix_one_offset<true>(v, lv - ln_g, mu, rg, g, &mphi, &rest, &da[mi]);
+            else tq_pix_one_offset<false>(v, lv - ln_g, mu, rg, g, &mphi, &rest, &da[mi]);
+            lp[mi] = rg * mphi + rest;
+          }
+          sv += v;
+          cnt += 1;
+          for (int k = 0; k < K; ++k) SN[k] += spot[k];
         } else {
+          for (int mi = 0; mi < M; ++mi) { lp[mi] = -INFINITY; da[mi] = 0; }
+        }
+        for (int mi = 0; mi < M; ++mi) gq[mi] = 0;
+      } else {
+        for (int mi = 0; mi < M; ++mi) {
+          float mu = b;
+          for (int k = 0; k < K; ++k)
+            if ((mi >> k) & 1) mu += spot[k];
           TqComboPix cp;
           TqLse acc;
           tq_combo_prepare(mu, rg, g, ln_g, &cp);
@@ -134,9 +151,9 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
           if (fast) tq_lse_finish<true>(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
           else tq_lse_finish<false>(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
         }
-        ll[mi] += lp[mi];
       }
-      if (bwd) {
+      for (int mi = 0; mi < M; ++mi) ll[mi] += lp[mi];
+      if (bwd && valid) {
         float q[K];
         for (int k = 0; k < K; ++k) q[k] = 0;
         for (int mi = 0; mi < M; ++mi) {
@@ -146,25 +163,40 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
           for (int k = 0; k < K; ++k)
             if ((mi >> k) & 1) q[k] += cw;
         }
+        const float r2 = fic * fic + fj * fj;
         for (int k = 0; k < K; ++k) {
-          const float aq = q[k] * spotn[k];
+          const float aq = q[k] * spot[k];
           S0[k] += aq;
-          S1x[k] += aq * dx[k];
-          S1y[k] += aq * dy[k];
-          S2[k] += aq * (dx[k] * dx[k] + dy[k] * dy[k]);
+          Sx[k] += aq * fic;
+          Sy[k] += aq * fj;
+          Sr[k] += aq * r2;
         }
       }
     }
-    for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = (float)ll[mi];
+    for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = (float)(ll[mi] + (one ? base : 0.0));
     if (bwd) {
       a.g_background[i] = (float)(acc_b * rg);
+      if (one) {
+        double Wsum = 0, mu_da = b * acc_b, mu_w = 0;
+        for (int mi = 0; mi < M; ++mi) Wsum += W[mi];
+        for (int k = 0; k < K; ++k) {
+          double Wk = 0;
+          for (int mi = 0; mi < M; ++mi)
+            if ((mi >> k) & 1) Wk += W[mi];
+          mu_da += S0[k];
+          mu_w += Wk * SN[k];
+        }
+        acc_g = rg * (mu_da + mu_w + Wsum * (b * cnt - sv));
+      }
       a.g_gain[i] = (float)(-acc_g * rg);
       for (int k = 0; k < K; ++k) {
-        const float rw = 1.0f / wk[k], hs = hk[k] * rg;
-        a.g_height[k * B + i] = (float)(S0[k] * rg);
-        a.g_x[k * B + i] = (float)(hs * S1x[k] * rw * rw);
-        a.g_y[k * B + i] = (float)(hs * S1y[k] * rw * rw);
-        a.g_width[k * B + i] = (float)(hs * (S2[k] * rw * rw * rw - 2.0 * S0[k] * rw));
+        const double rw = 1.0 / wk[k];
+        const double S1x = Sx[k] - cx[k] * S0[k], S1y = Sy[k] - cy[k] * S0[k];
+        const double S2 = Sr[k] - 2.0 * (cx[k] * Sx[k] + cy[k] * Sy[k]) + ((double)cx[k] * cx[k] + (double)cy[k] * cy[k]) * S0[k];
+        a.g_height[k * B + i] = (float)(S0[k] * rg / hk[k]);
+        a.g_x[k * B + i] = (float)(rg * S1x * rw * rw);
+        a.g_y[k * B + i] = (float)(rg * S1y * rw * rw);
+        a.g_width[k * B + i] = (float)(rg * (S2 * rw * rw * rw - 2.0 * S0[k] * rw));
       }
     }
   }
