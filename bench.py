@@ -55,7 +55,9 @@ def time_pixel_kernel(eng, launches, backward):
     B = eng.Nt * eng.F * eng.C
     k = _lib.KsmognArgs()
     p = _lib.ptr
-    k.images, k.xy, k.ndx, k.fdx = p(eng.images), p(eng.xy), None, None
+    k.images, k.images_il, k.xy, k.ndx, k.fdx = p(eng.images), p(eng.images_il), p(eng.xy), None, None
+    k.nb_full, k.il_min_units = eng.Nt, eng.il_min_units
+    k.pixstats, k.stats_stride = p(eng.pixstats), B
     lat = eng.lat
     f = lambda row: lat.data_ptr() + 4 * row * B
     k.background, k.height, k.width, k.x, k.y = f(0), f(1), f(1 + K), f(1 + 2 * K), f(1 + 3 * K)

@@ -56,6 +56,10 @@ const char* tq_last_error(void);
  * ------------------------------------------------------------------------------------- */
 typedef struct {
   const float* images;         /* (Nt, F, C, P, P) */
+  const float* images_il;      /* the same images in the 64-unit interleaved layout of tq_images_interleave, or
+                                  NULL.  Used for contiguous batches (ndx == fdx == NULL, nb == nb_full, fb == F) */
+  const float* pixstats;       /* [3][stats_stride] per-unit data statistics of tq_image_stats (dataset-indexed), or
+                                  NULL.  With O == 1 they enable the single-offset formulation (tq_pixel.h) */
   const float* xy;             /* (Nt, F, C, 2) target locations (x, y) */
   const int32_t* ndx;          /* [nb] AOI indices or NULL */
   const int32_t* fdx;          /* [fb] frame indices or NULL */
@@ -78,12 +82,27 @@ typedef struct {
   float* g_y;                  /* [K][B] out */
   float* g_gain;               /* [B]    out: per-unit partial of d/d gain */
   int64_t m_kstride;           /* = Nt*F*C */
+  int64_t stats_stride;        /* = Nt*F*C (row stride of pixstats) */
   int32_t nb, fb, C, F;        /* minibatch and dataset geometry */
   int32_t P, K, O;
+  int32_t nb_full;             /* Nt of the dataset behind images_il */
+  int32_t il_min_units;        /* use the interleaved kernel only for batches of at least this many units */
   float scale;                 /* plate scale (Nt/nb)(F/fb), used with m_logit */
 } tq_ksmogn_args;
 
 int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
+
+/* Tile-interleaved copy of the image tensor for the contiguous-batch kernel: units in blocks of 64,
+ * pixels in groups of 4, so that a wave64 reads one contiguous 1 KiB row per load:
+ *   out[((u / 64) * npix4 + q) * 64 + (u % 64)] = float4{ pixels 4q..4q+3 of unit u },  npix4 = ceil(P*P/4)
+ * `out` must hold tq_interleaved_floats(U, P) floats. */
+int64_t tq_interleaved_floats(int64_t U, int32_t P);
+int tq_images_interleave(const float* images, float* images_il, int64_t U, int32_t P, void* stream);
+
+/* Per-unit data statistics for a single camera offset `offset[0]` (device scalar): with v = D - offset,
+ *   pixstats[0][u] = sum_pix v,  pixstats[1][u] = sum_pix ln v,  pixstats[2][u] = #pixels with v <= 0
+ * (a unit with such a pixel has log-likelihood -inf, ksmogn.py:226).  pixstats holds 3*U floats. */
+int tq_image_stats(const float* images, const float* offset, float* pixstats, int64_t U, int32_t P, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * One SVI step of the cosmos model = what `self.svi.step()` does at
@@ -106,6 +125,8 @@ int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
 typedef struct {
   /* dataset (device) */
   const float* images;         /* (Nt, F, C, P, P) */
+  const float* images_il;      /* interleaved copy (tq_images_interleave) or NULL */
+  const float* pixstats;       /* [3][Nt*F*C] data statistics (tq_image_stats) when O == 1, else NULL */
   const float* xy;             /* (Nt, F, C, 2) */
   const uint8_t* is_ontarget;  /* [Nt] */
   const uint8_t* aoi_mask;     /* [Nt] or NULL */
@@ -137,6 +158,7 @@ typedef struct {
   int32_t n_offset;            /* global index of local AOI 0 (AOI sharding: RNG streams use global ids) */
   int32_t draw_globals;        /* 1: draw the global base variates; 0: use the contents of gbase */
   int32_t draw_locals;         /* 1: draw b, h, w, x, y; 0: use the contents of lat (parity tests) */
+  int32_t il_min_units;        /* contiguous batches of at least this many units use the interleaved pixel kernel */
   float scale_n;               /* Nt_global / nb_global */
   float scale;                 /* scale_n * F / fb */
   float global_weight;         /* weight of the global ELBO part on this rank (1 on exactly one rank for reporting) */

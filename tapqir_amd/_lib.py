@@ -25,16 +25,17 @@ class KsmognArgs(C.Structure):
     """``tq_ksmogn_args`` (include/tapqir_hip.h)."""
 
     _fields_ = [
-        ("images", C.c_void_p), ("xy", C.c_void_p), ("ndx", C.c_void_p), ("fdx", C.c_void_p),
-        ("background", C.c_void_p), ("height", C.c_void_p), ("width", C.c_void_p),
+        ("images", C.c_void_p), ("images_il", C.c_void_p), ("pixstats", C.c_void_p), ("xy", C.c_void_p),
+        ("ndx", C.c_void_p), ("fdx", C.c_void_p), ("background", C.c_void_p), ("height", C.c_void_p), ("width", C.c_void_p),
         ("x", C.c_void_p), ("y", C.c_void_p), ("gain", C.c_void_p),
         ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
         ("gout", C.c_void_p), ("m_logit", C.c_void_p), ("aoi_mask", C.c_void_p),
         ("ll", C.c_void_p), ("g_background", C.c_void_p), ("g_height", C.c_void_p),
         ("g_width", C.c_void_p), ("g_x", C.c_void_p), ("g_y", C.c_void_p), ("g_gain", C.c_void_p),
-        ("m_kstride", C.c_int64),
+        ("m_kstride", C.c_int64), ("stats_stride", C.c_int64),
         ("nb", C.c_int32), ("fb", C.c_int32), ("C", C.c_int32), ("F", C.c_int32),
         ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
+        ("nb_full", C.c_int32), ("il_min_units", C.c_int32),
         ("scale", C.c_float),
     ]
 
@@ -43,14 +44,15 @@ class CosmosArgs(C.Structure):
     """``tq_cosmos_args`` (include/tapqir_hip.h)."""
 
     _fields_ = [
-        ("images", C.c_void_p), ("xy", C.c_void_p), ("is_ontarget", C.c_void_p), ("aoi_mask", C.c_void_p),
+        ("images", C.c_void_p), ("images_il", C.c_void_p), ("pixstats", C.c_void_p), ("xy", C.c_void_p),
+        ("is_ontarget", C.c_void_p), ("aoi_mask", C.c_void_p),
         ("ndx", C.c_void_p), ("fdx", C.c_void_p), ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
         ("params", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
         ("lat", C.c_void_p), ("site", C.c_void_p), ("pix", C.c_void_p), ("aoi_part", C.c_void_p), ("blk_part", C.c_void_p),
         ("gsum", C.c_void_p), ("globals", C.c_void_p), ("gbase", C.c_void_p), ("elbo_out", C.c_void_p),
         ("Nt", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
         ("nb", C.c_int32), ("fb", C.c_int32), ("n_offset", C.c_int32), ("draw_globals", C.c_int32),
-        ("draw_locals", C.c_int32),
+        ("draw_locals", C.c_int32), ("il_min_units", C.c_int32),
         ("scale_n", C.c_float), ("scale", C.c_float), ("global_weight", C.c_float),
         ("eps", C.c_float),
         ("width_min", C.c_float), ("width_max", C.c_float), ("height_std", C.c_float),
@@ -65,7 +67,7 @@ class CosmosArgs(C.Structure):
 
 # every symbol include/tapqir_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "tq_version", "tq_last_error", "tq_ksmogn_log_prob",
+    "tq_version", "tq_last_error", "tq_ksmogn_log_prob", "tq_interleaved_floats", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step",
@@ -96,6 +98,12 @@ def load():
     lib.tq_cosmos_nblk.argtypes = [C.c_int64]
     lib.tq_cosmos_param_count.restype = C.c_int64
     lib.tq_cosmos_param_count.argtypes = [C.c_int32] * 4
+    lib.tq_interleaved_floats.restype = C.c_int64
+    lib.tq_interleaved_floats.argtypes = [C.c_int64, C.c_int32]
+    lib.tq_images_interleave.restype = C.c_int
+    lib.tq_images_interleave.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    lib.tq_image_stats.restype = C.c_int
+    lib.tq_image_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.tq_ksmogn_log_prob.argtypes = [C.POINTER(KsmognArgs), C.c_void_p]
     lib.tq_ksmogn_log_prob.restype = C.c_int
     for name in ("tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",

@@ -189,7 +189,11 @@ extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) {
   const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
   // 1. pixel kernel: fused render + log-likelihood + pathwise gradients, Dice weights from m_probs
   tq_ksmogn_args k = {};
-  k.images = a->images; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
+  k.images = a->images; k.images_il = a->images_il; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
+  k.nb_full = a->Nt;
+  k.pixstats = a->pixstats;
+  k.stats_stride = U;
+  k.il_min_units = a->il_min_units;  // below ~1 wave per SIMD the 16-lanes-per-unit kernel has more parallelism
   k.background = a->lat;
   k.height = a->lat + (int64_t)1 * B;
   k.width = a->lat + (int64_t)(1 + K) * B;

@@ -2,19 +2,23 @@
 // for CDNA4 / gfx950.  Replaces tapqir/distributions/ksmogn.py:146-238 and
 // tapqir/distributions/util.py:15-64 (see include/tapqir_hip.h).
 //
-// Mapping.  wave64 = 4 units x 16 lanes; a 256-thread workgroup owns 16 consecutive units, so
-// the 16 P*P tiles it reads are one contiguous span of the (Nt,F,C,P,P) tensor when the
-// minibatch is contiguous.  Lane r of a unit walks pixels r, r+16, ... (P=14: 13 trips, 94 %
-// of lanes busy; P=20: 25 trips, 100 %).  The (2^K, ..., K, P, P) Gaussian stack of the
-// reference is never materialised: per unit the 2*K*P separable factors exp(-(p-c)^2/2w^2)
-// are computed once into LDS (2P exps per spot instead of P^2) and every pixel forms
-// mu(m) = b + sum_{k in m} A_k Gx_k[i] Gy_k[j] for all 2^K presence combinations in registers.
-// Pixel sums (log-likelihood per combination + the weighted gradient moments) are reduced
-// over the 16 lanes with wave shuffles; no atomics, no global scratch.
+// The (2^K, ..., K, P, P) Gaussian stack and the (..., P, P, O) mixture tensor of the reference are
+// never materialised: every pixel forms mu(m) = b + sum_{k in m} A_k Gx_k[i] Gy_k[j] for all 2^K
+// spot-presence combinations in registers, evaluates the log-density and (optionally) its gradient,
+// and only per-unit sums leave the kernel.  Two mappings share the per-pixel code:
+//
+//   tq_ksmogn_il_kernel  (contiguous batches, the full-batch SVI step)
+//       one LANE per unit on a tile-interleaved copy of the images: a wave64 reads its 64 tiles with
+//       one fully coalesced 1 KiB global_load_dwordx4 per 4 pixels (next rows prefetched), no LDS, no
+//       cross-lane reduction, wave-uniform pixel coordinates, unit-contiguous parameter loads/stores.
+//   tq_ksmogn_kernel     (gathered minibatches, small batches, the plain KSMOGN.log_prob API)
+//       16 lanes per unit, 16 units per 256-thread workgroup; the P x P tile is staged through LDS
+//       with 16 B loads, the 2*K*P separable Gaussian factors are computed once per unit into LDS,
+//       pixel sums are reduced over the 16 lanes of a DPP row.
 //
 // Not MFMA work: there is no contraction, only transcendental-heavy pointwise math and a
-// 196-term reduction; the roofline that bounds it is HBM (algorithmic 844 B/unit at
-// K=2,P=14) vs the quarter-rate transcendental pipe -- see DESIGN.md.
+// P*P-term reduction; the roofline that bounds it is HBM (algorithmic 844 B/unit at K=2,P=14)
+// vs the quarter-rate transcendental pipe -- see DESIGN.md.
 #include <hip/hip_runtime.h>
 
 #include "../../include/tapqir_hip.h"
@@ -38,62 +42,56 @@ __device__ __forceinline__ float tq_group_sum16(float v) {
 }
 __device__ __forceinline__ float tq_fast_sigmoid(float u) { return TQ_FRCP(1.0f + TQ_FEXP(-u)); }
 
-// LDS: [16 units][tile stride] staged pixels, then [16 units][2K][P] separable Gaussian factors.
+// LDS of the 16-lane kernel: [16 units][tile stride] staged pixels, then [16 units][2K][P] factors.
 // The tile stride is npix rounded up to 16 (mod 32) floats so that the two units sharing a
 // 32-lane ds_read_b32 group hit disjoint bank halves.
 __host__ __device__ inline int tq_tile_stride(int npix) { return ((npix + 15) / 32) * 32 + 16; }
 
-// per-lane accumulators of the pixel loop
+// ---- per-lane accumulators of the pixel loop ------------------------------------------------------
 template <int K>
 struct TqPixAcc {
-  float ll[1 << K];   // general path: log-likelihood per combination.  Single-offset path: the
-                      // "rest" part (1/2 ln alpha - S) for combinations >= 1 (entry 0 unused)
-  float mphi[1 << K]; // single-offset path: sum mu*phi per combination (entry 0: sum phi of combination 0)
-  float base;         // single-offset path: sum ln v (the combination-independent part)
-  float acc_b;        // sum_m W_m da_m
-  float acc_g;        // general path only: sum_m W_m [alpha (da+1) - E_o v / g]
-  float sv, cnt;      // single-offset path: sum v, number of valid pixels
+  // single-offset path, combinations mi >= 1 (tq_pixel.h): sums of mu*log2(v/mu), log2(v/mu), S(alpha)
+  // general path: ll[mi] = log-likelihood per combination, the other two unused
+  float ll[1 << K], sl[1 << K], sS[1 << K];
+  float acc_b;                       // sum_m W_m da_m                (combination 0 added analytically)
+  float acc_g;                       // general path only: sum_m W_m [alpha (da+1) - E_o v / g]
   float S0[K], Sx[K], Sy[K], Sr[K];  // spot-weighted moments: sum q*spot*{1, i, j, i^2+j^2}
-  float SN[K];        // single-offset path: sum spot_k over valid pixels
-  float bad;          // single-offset path: > 0 if the unit has a pixel at or below the offset (log 0)
+  float SN[K];                       // single-offset path: sum spot_k
 };
 
-// One pixel, single-offset path.  CHECK = some lane of the wave has D <= offset (masked pixel).
-template <int K, bool BWD, bool FAST, bool CHECK>
-__device__ __forceinline__ void tq_pixel_one_offset(TqPixAcc<K>& A, float v, bool ok, float ln_g,
-                                                    float b, const float* spot, const float* W, float fic, float fj,
-                                                    const TqCombo0& c0, float g, float rg) {
+template <int K>
+__device__ __forceinline__ void tq_acc_zero(TqPixAcc<K>& A) {
+#pragma unroll
+  for (int mi = 0; mi < (1 << K); ++mi) A.ll[mi] = A.sl[mi] = A.sS[mi] = 0.0f;
+  A.acc_b = A.acc_g = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) A.S0[k] = A.Sx[k] = A.Sy[k] = A.Sr[k] = A.SN[k] = 0.0f;
+}
+
+// One pixel, single-offset path (the unit's data statistics cover everything else).
+template <int K, bool BWD, bool FAST>
+__device__ __forceinline__ void tq_pixel_one_offset(TqPixAcc<K>& A, float v, float b, const float* spot, const float* W,
+                                                    float fic, float fj, float g, float rg, float ln_g) {
   constexpr int M = 1 << K;
-  if (CHECK && !ok) {
-    A.bad = 1.0f;  // log 0 for every combination; the pixel contributes no gradient
-    return;
-  }
-  const float lv = TQ_FLOG(v);
-  A.base += lv;
-  const float lvg = lv - ln_g;
   float da[M];
-  {
-    float phi0;
-    tq_pix_combo0(c0, v, lv, &phi0, &da[0]);
-    A.mphi[0] += phi0;
-  }
 #pragma unroll
   for (int mi = 1; mi < M; ++mi) {
     float mu = b;
 #pragma unroll
     for (int k = 0; k < K; ++k)
       if ((mi >> k) & 1) mu += spot[k];
-    float mphi, rest;
-    tq_pix_one_offset<FAST>(v, lvg, mu, rg, g, &mphi, &rest, &da[mi]);
-    A.mphi[mi] += mphi;
-    A.ll[mi] += rest;
+    float l2, S;
+    tq_pix_one_offset<FAST>(v, mu, g, rg, ln_g, &l2, &S, &da[mi]);
+    A.ll[mi] += mu * l2;
+    A.sl[mi] += l2;
+    A.sS[mi] += S;
   }
   if (BWD) {
     float q[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) q[k] = 0.0f;
 #pragma unroll
-    for (int mi = 0; mi < M; ++mi) {
+    for (int mi = 1; mi < M; ++mi) {
       const float cw = W[mi] * da[mi];
       A.acc_b += cw;
 #pragma unroll
@@ -108,11 +106,10 @@ __device__ __forceinline__ void tq_pixel_one_offset(TqPixAcc<K>& A, float v, boo
       A.Sx[k] += aq * fic;
       A.Sy[k] += aq * fj;
       A.Sr[k] += aq * r2;
-      A.SN[k] += spot[k];
     }
-    A.sv += v;
   }
-  A.cnt += 1.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) A.SN[k] += spot[k];
 }
 
 // One pixel, general path: online log-sum-exp over the offset samples.
@@ -171,14 +168,113 @@ __device__ __forceinline__ void tq_pixel_multi_offset(TqPixAcc<K>& A, const tq_k
   }
 }
 
+// Single-offset path: assemble log p(m) and the combination-0 gradient part from the running sums and
+// the unit's data statistics (formulas in tq_pixel.h).
+template <int K, bool BWD>
+__device__ __forceinline__ void tq_pixel_assemble_one_offset(const tq_ksmogn_args& a, TqPixAcc<K>& A, const float* W,
+                                                             float b, float g, float rg, float ln_g, float fnpix,
+                                                             float S_v, float S_lv) {
+  constexpr int M = 1 << K;
+  TqCombo0 c0;
+  tq_combo0_prepare(b, rg, g, ln_g, &c0);
+  const float lw0 = a.offset_logits[0] - TQ_LN_SQRT_2PI;
+  const float common = lw0 * fnpix - S_lv;             // sum [ln w - ln sqrt(2pi) - ln v]
+  const float S_lvg = S_lv - fnpix * ln_g;             // sum [ln v - ln g]
+  const float sl0 = S_lv - fnpix * c0.lnb;             // sum ln(v / b)
+  const float mu_minus_v0 = b * fnpix - S_v;           // sum (b - v)
+  A.ll[0] = common + rg * (b * sl0 + mu_minus_v0) + 0.5f * (S_lvg - sl0) - fnpix * c0.S;
+#pragma unroll
+  for (int mi = 1; mi < M; ++mi) {
+    float sn = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if ((mi >> k) & 1) sn += A.SN[k];
+    A.ll[mi] = common + rg * (TQ_LN2 * A.ll[mi] + mu_minus_v0 + sn) + 0.5f * (S_lvg - TQ_LN2 * A.sl[mi]) - A.sS[mi];
+  }
+  if (BWD) A.acc_b += W[0] * (sl0 + fnpix * c0.c_da);  // sum_pix W_0 da_0
+}
+
+// Turn the (already lane-reduced) pixel sums of one unit into its outputs.
+template <int K, bool ONE_OFFSET, bool BWD>
+__device__ __forceinline__ void tq_pixel_store(const tq_ksmogn_args& a, int64_t B, int64_t i, const TqPixAcc<K>& A,
+                                               const float* W, float b, float rg, const float* hk, const float* wk,
+                                               const float* cx, const float* cy, float fnpix, float S_v, bool bad) {
+  constexpr int M = 1 << K;
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = bad ? -INFINITY : A.ll[mi];
+  if (BWD) {
+    const float z = bad ? 0.0f : 1.0f;  // a unit with a pixel at or below the offset has log p = -inf: no gradient
+    // d alpha = d mu / g for every mu-parameter
+    a.g_background[i] = z * A.acc_b * rg;
+    float acc_g = A.acc_g;
+    if (ONE_OFFSET) {
+      // sum_m W_m [alpha_m (da_m + 1) - v/g] = (1/g) [ sum_m W_m mu_m da_m + sum_m W_m mu_m - (sum_m W_m) v ]
+      float Wsum = 0.0f, mu_da = b * A.acc_b, mu_w = 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < M; ++mi) Wsum += W[mi];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float Wk = 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < M; ++mi)
+          if ((mi >> k) & 1) Wk += W[mi];
+        mu_da += A.S0[k];
+        mu_w += Wk * A.SN[k];
+      }
+      acc_g = rg * (mu_da + mu_w + Wsum * (b * fnpix - S_v));
+    }
+    a.g_gain[i] = -z * acc_g * rg;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float rw = TQ_FRCP(wk[k]);
+      const float S1x = A.Sx[k] - cx[k] * A.S0[k];
+      const float S1y = A.Sy[k] - cy[k] * A.S0[k];
+      const float S2 = A.Sr[k] - 2.0f * (cx[k] * A.Sx[k] + cy[k] * A.Sy[k]) + (cx[k] * cx[k] + cy[k] * cy[k]) * A.S0[k];
+      a.g_height[k * B + i] = z * A.S0[k] * rg * TQ_FRCP(hk[k]);
+      a.g_x[k * B + i] = z * rg * S1x * rw * rw;
+      a.g_y[k * B + i] = z * rg * S1y * rw * rw;
+      a.g_width[k * B + i] = z * rg * (S2 * rw * rw * rw - 2.0f * A.S0[k] * rw);
+    }
+  }
+}
+
+// Dice weights of the cosmos guide (or the caller's upstream weights)
+template <int K>
+__device__ __forceinline__ void tq_load_weights(const tq_ksmogn_args& a, int64_t B, int64_t i, int64_t u, int n,
+                                                float* W) {
+  constexpr int M = 1 << K;
+  if (a.gout) {
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) W[mi] = a.gout[(int64_t)mi * B + i];
+  } else {
+    float p1[K], p0[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float uk = a.m_logit[k * a.m_kstride + u];
+      p1[k] = tq_fast_sigmoid(uk);
+      p0[k] = tq_fast_sigmoid(-uk);
+    }
+    const float sc = a.scale * ((a.aoi_mask == nullptr || a.aoi_mask[n]) ? 1.0f : 0.0f);
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) {
+      float w = sc;
+#pragma unroll
+      for (int k = 0; k < K; ++k) w *= ((mi >> k) & 1) ? p1[k] : p0[k];
+      W[mi] = w;
+    }
+  }
+}
+
+// =============================================================================================
+// 16 lanes per unit
+// =============================================================================================
 template <int K, bool ONE_OFFSET, bool BWD, bool FAST>
 __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_args& a,
                                               const float* __restrict__ s_tile, const float* __restrict__ s_fac,
                                               int r, int P, int npix, float b, const float* amph, float g, float rg,
-                                              float ln_g, const float* W, const TqCombo0& c0) {
+                                              float ln_g, const float* W) {
   const uint32_t magic = (1u << 20) / (uint32_t)P + 1u;  // exact pix / P for pix < 4096, P <= 64
   const float off0 = a.offset_samples[0];
-
   for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
     const int j = (int)(((uint32_t)pix * magic) >> 20);
     const int ic = pix - j * P;
@@ -187,17 +283,8 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
     float spot[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) spot[k] = amph[k] * s_fac[(2 * k) * TQ_MAX_P + ic] * s_fac[(2 * k + 1) * TQ_MAX_P + j];
-
-    if (ONE_OFFSET) {
-      const float v = D - off0;
-      const bool ok = v > 0.0f;
-      // every pixel of real data exceeds the offset (glimpse_reader.py:407-411); one wave-uniform
-      // test keeps the per-lane predication out of the common path
-      if (__all(ok)) tq_pixel_one_offset<K, BWD, FAST, false>(A, v, ok, ln_g, b, spot, W, fic, fj, c0, g, rg);
-      else tq_pixel_one_offset<K, BWD, FAST, true>(A, v, ok, ln_g, b, spot, W, fic, fj, c0, g, rg);
-    } else {
-      tq_pixel_multi_offset<K, BWD, FAST>(A, a, D, ln_g, b, spot, W, fic, fj, g, rg);
-    }
+    if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, D - off0, b, spot, W, fic, fj, g, rg, ln_g);
+    else tq_pixel_multi_offset<K, BWD, FAST>(A, a, D, ln_g, b, spot, W, fic, fj, g, rg);
   }
 }
 
@@ -271,30 +358,9 @@ __global__ __launch_bounds__(TQ_BLOCK, TQ_PIX_WAVES) void tq_ksmogn_kernel(const
     }
   }
 
-  // ---- upstream weights ---------------------------------------------------------------------
   float W[M];
-  if (BWD) {
-    if (a.gout) {
-#pragma unroll
-      for (int mi = 0; mi < M; ++mi) W[mi] = a.gout[(int64_t)mi * B + i];
-    } else {
-      float p1[K], p0[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float uk = a.m_logit[k * a.m_kstride + u];
-        p1[k] = tq_fast_sigmoid(uk);
-        p0[k] = tq_fast_sigmoid(-uk);
-      }
-      const float sc = a.scale * ((a.aoi_mask == nullptr || a.aoi_mask[n]) ? 1.0f : 0.0f);
-#pragma unroll
-      for (int mi = 0; mi < M; ++mi) {
-        float w = sc;
-#pragma unroll
-        for (int k = 0; k < K; ++k) w *= ((mi >> k) & 1) ? p1[k] : p0[k];
-        W[mi] = w;
-      }
-    }
-  }
+  if (BWD) tq_load_weights<K>(a, B, i, u, n, W);
+
   // the tile and the factor table of a unit are written and read by the same 16 lanes of ONE wave:
   // LDS operations of a wave complete in order, so no workgroup barrier is needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -303,120 +369,462 @@ __global__ __launch_bounds__(TQ_BLOCK, TQ_PIX_WAVES) void tq_ksmogn_kernel(const
 
   // ---- pixel loop -----------------------------------------------------------------------------
   TqPixAcc<K> A;
-#pragma unroll
-  for (int mi = 0; mi < M; ++mi) A.ll[mi] = A.mphi[mi] = 0.0f;
-  A.base = A.acc_b = A.acc_g = A.sv = A.cnt = A.bad = 0.0f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) A.S0[k] = A.Sx[k] = A.Sy[k] = A.Sr[k] = A.SN[k] = 0.0f;
-  TqCombo0 c0;
-  if (ONE_OFFSET) tq_combo0_prepare(b, rg, g, ln_g, &c0);
-
+  tq_acc_zero<K>(A);
   // alpha(m) >= background / gain for every combination and pixel: one wave-uniform test picks
   // the branch-free loop (one-term Binet correction valid) or the general one
-  if (__all(b * rg >= TQ_FAST_ALPHA))
-    tq_pixel_loop<K, ONE_OFFSET, BWD, true>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, c0);
-  else
-    tq_pixel_loop<K, ONE_OFFSET, BWD, false>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, c0);
+  if (__all(b * rg >= TQ_FAST_ALPHA)) tq_pixel_loop<K, ONE_OFFSET, BWD, true>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W);
+  else tq_pixel_loop<K, ONE_OFFSET, BWD, false>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W);
 
-  // ---- reduce over the unit's 16 lanes and store ------------------------------------------------
-  if (ONE_OFFSET) {
-    // log p = [ln w - ln sqrt(2pi) - ln v] + (1/g) mu phi + rest ; combination 0: alpha0 phi + c_lp
-    const float lw0 = a.offset_logits[0] - TQ_LN_SQRT_2PI;
-    const float common = lw0 * A.cnt - A.base;
-    A.ll[0] = common + c0.alpha * A.mphi[0] + c0.c_lp * A.cnt;
+  // ---- reduce over the unit's 16 lanes, assemble and store ------------------------------------------
 #pragma unroll
-    for (int mi = 1; mi < M; ++mi) A.ll[mi] += common + rg * A.mphi[mi];
-    A.bad = tq_group_sum16(A.bad);
-  }
-#pragma unroll
-  for (int mi = 0; mi < M; ++mi) A.ll[mi] = tq_group_sum16(A.ll[mi]);
-  if (ONE_OFFSET && A.bad > 0.0f) {
-#pragma unroll
-    for (int mi = 0; mi < M; ++mi) A.ll[mi] = -INFINITY;
+  for (int mi = 0; mi < M; ++mi) {
+    A.ll[mi] = tq_group_sum16(A.ll[mi]);
+    if (ONE_OFFSET) {
+      A.sl[mi] = tq_group_sum16(A.sl[mi]);
+      A.sS[mi] = tq_group_sum16(A.sS[mi]);
+    }
   }
   if (BWD) {
     A.acc_b = tq_group_sum16(A.acc_b);
-    if (ONE_OFFSET) {
-      A.sv = tq_group_sum16(A.sv);
-      A.cnt = tq_group_sum16(A.cnt);
-    } else {
-      A.acc_g = tq_group_sum16(A.acc_g);
-    }
+    if (!ONE_OFFSET) A.acc_g = tq_group_sum16(A.acc_g);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       A.S0[k] = tq_group_sum16(A.S0[k]);
       A.Sx[k] = tq_group_sum16(A.Sx[k]);
       A.Sy[k] = tq_group_sum16(A.Sy[k]);
       A.Sr[k] = tq_group_sum16(A.Sr[k]);
-      if (ONE_OFFSET) A.SN[k] = tq_group_sum16(A.SN[k]);
     }
   }
-  if (live && r == 0) {
+  float S_v = 0.0f;
+  bool bad = false;
+  if (ONE_OFFSET) {
 #pragma unroll
-    for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = A.ll[mi];
-    if (BWD) {
-      // d alpha = d mu / g for every mu-parameter
-      a.g_background[i] = A.acc_b * rg;
-      float acc_g = A.acc_g;
-      if (ONE_OFFSET) {
-        // sum_m W_m [alpha_m (da_m + 1) - v/g] = (1/g) [ sum_m W_m mu_m da_m + sum_m W_m mu_m - (sum_m W_m) v ]
-        float Wsum = 0.0f, mu_da = b * A.acc_b, mu_w = 0.0f;
+    for (int k = 0; k < K; ++k) A.SN[k] = tq_group_sum16(A.SN[k]);
+    S_v = a.pixstats[u];
+    const float S_lv = a.pixstats[a.stats_stride + u];
+    bad = a.pixstats[2 * a.stats_stride + u] > 0.0f;
+    tq_pixel_assemble_one_offset<K, BWD>(a, A, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
+  }
+  if (live && r == 0) tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cx, cy, (float)npix, S_v, bad);
+}
+
+// =============================================================================================
+// Lane-per-unit variant for CONTIGUOUS batches (ndx == fdx == NULL: minibatch unit i = dataset unit i).
+//
+// Image layout (built once per dataset by tq_images_interleave): units are grouped in blocks of 64,
+// and within a block the pixels are interleaved so that the j-th group of 4 pixels of the 64 units is
+// one contiguous 1 KiB row:
+//     images_il[((u / 64) * npix4 + q) * 64 + (u % 64)] = float4{ pixels 4q .. 4q+3 of unit u },  npix4 = ceil(P*P / 4)
+// Per pixel each lane evaluates exp for the x-factor of each spot (the y-factor is per row);
+// everything else is the same per-pixel code as above.
+// =============================================================================================
+template <int K, bool ONE_OFFSET, bool BWD, bool FAST>
+__device__ __forceinline__ void tq_il_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_args& a, const float4* __restrict__ src,
+                                                 int P, int npix, float b, const float* amph, const float* nl2,
+                                                 const float* cx, const float* cy, float g, float rg, float ln_g,
+                                                 const float* W) {
+  const int npix4 = (npix + 3) >> 2;
+  const float off0 = a.offset_samples[0];
+  int ic = 0, jr = 0;  // wave-uniform pixel coordinates
+  float fj = 0.0f, agy[K];
 #pragma unroll
-        for (int mi = 0; mi < M; ++mi) Wsum += W[mi];
+  for (int k = 0; k < K; ++k) agy[k] = amph[k] * __builtin_amdgcn_exp2f(cy[k] * cy[k] * nl2[k]);
+
+  // one group of 4 pixels held in a float4
+  auto group = [&](const float4& d, int q) {
+    const float d4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (4 * q + e < npix) {
+        const float fic = (float)ic;
+        float spot[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          float Wk = 0.0f;
-#pragma unroll
-          for (int mi = 0; mi < M; ++mi)
-            if ((mi >> k) & 1) Wk += W[mi];
-          mu_da += A.S0[k];
-          mu_w += Wk * A.SN[k];
+          const float dx = fic - cx[k];
+          spot[k] = agy[k] * __builtin_amdgcn_exp2f(dx * dx * nl2[k]);
         }
-        acc_g = rg * (mu_da + mu_w + Wsum * (b * A.cnt - A.sv));
-      }
-      a.g_gain[i] = -acc_g * rg;
+        if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, d4[e] - off0, b, spot, W, fic, fj, g, rg, ln_g);
+        else tq_pixel_multi_offset<K, BWD, FAST>(A, a, d4[e], ln_g, b, spot, W, fic, fj, g, rg);
+        if (++ic == P) {  // next row: refresh the y-factors
+          ic = 0;
+          ++jr;
+          fj = (float)jr;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float rw = TQ_FRCP(wk[k]);
-        const float S1x = A.Sx[k] - cx[k] * A.S0[k];
-        const float S1y = A.Sy[k] - cy[k] * A.S0[k];
-        const float S2 = A.Sr[k] - 2.0f * (cx[k] * A.Sx[k] + cy[k] * A.Sy[k]) + (cx[k] * cx[k] + cy[k] * cy[k]) * A.S0[k];
-        a.g_height[k * B + i] = A.S0[k] * rg * TQ_FRCP(hk[k]);
-        a.g_x[k * B + i] = rg * S1x * rw * rw;
-        a.g_y[k * B + i] = rg * S1y * rw * rw;
-        a.g_width[k * B + i] = rg * (S2 * rw * rw * rw - 2.0f * A.S0[k] * rw);
+          for (int k = 0; k < K; ++k) {
+            const float dy = fj - cy[k];
+            agy[k] = amph[k] * __builtin_amdgcn_exp2f(dy * dy * nl2[k]);
+          }
+        }
       }
     }
+  };
+  // three named registers in rotation: each is reloaded right after it has been consumed, so two
+  // 1 KiB rows per wave are always in flight and no register move (hence no vmcnt(0)) is needed
+  float4 r0 = src[0];
+  float4 r1 = npix4 > 1 ? src[64] : r0;
+  float4 r2 = npix4 > 2 ? src[128] : r0;
+  for (int q = 0; q < npix4; q += 3) {
+    group(r0, q);
+    if (q + 3 < npix4) r0 = src[(int64_t)(q + 3) * 64];
+    if (q + 1 < npix4) {
+      group(r1, q + 1);
+      if (q + 4 < npix4) r1 = src[(int64_t)(q + 4) * 64];
+    }
+    if (q + 2 < npix4) {
+      group(r2, q + 2);
+      if (q + 5 < npix4) r2 = src[(int64_t)(q + 5) * 64];
+    }
+  }
+}
+
+template <int K, bool ONE_OFFSET, bool BWD>
+__global__ __launch_bounds__(256) void tq_ksmogn_il_kernel(const tq_ksmogn_args a, const int64_t B) {
+  constexpr int M = 1 << K;
+  const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i_raw < B;
+  const int64_t i = live ? i_raw : (B - 1);  // idle lanes of the last wave shadow the last unit
+  const int P = a.P, npix = P * P;
+  const int npix4 = (npix + 3) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i_raw >> 6) * npix4) * 64 + (i_raw & 63);
+
+  const float g = a.gain[0];
+  const float rg = TQ_FRCP(g);
+  const float ln_g = TQ_FLOG(g);
+  const float tx = a.xy[2 * i], ty = a.xy[2 * i + 1];
+  const float b = a.background[i];
+  float hk[K], wk[K], amph[K], nl2[K], cx[K], cy[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    hk[k] = a.height[k * B + i];
+    wk[k] = a.width[k * B + i];
+    cx[k] = a.x[k * B + i] + tx;
+    cy[k] = a.y[k * B + i] + ty;
+    const float inv2v = 0.5f * TQ_FRCP(wk[k] * wk[k]);
+    amph[k] = hk[k] * inv2v * (1.0f / TQ_PI);  // h / (2 pi w^2)
+    nl2[k] = -inv2v * 1.44269504088896340736f;  // exp(-d^2/(2w^2)) = exp2(d^2 * nl2)
+  }
+  float W[M];
+  if (BWD) tq_load_weights<K>(a, B, i, i, (int)((uint32_t)i / (uint32_t)(a.F * a.C)), W);
+
+  TqPixAcc<K> A;
+  tq_acc_zero<K>(A);
+  if (__all(b * rg >= TQ_FAST_ALPHA)) tq_il_pixel_loop<K, ONE_OFFSET, BWD, true>(A, a, src, P, npix, b, amph, nl2, cx, cy, g, rg, ln_g, W);
+  else tq_il_pixel_loop<K, ONE_OFFSET, BWD, false>(A, a, src, P, npix, b, amph, nl2, cx, cy, g, rg, ln_g, W);
+
+  float S_v = 0.0f;
+  bool bad = false;
+  if (ONE_OFFSET) {
+    S_v = a.pixstats[i];
+    const float S_lv = a.pixstats[a.stats_stride + i];
+    bad = a.pixstats[2 * a.stats_stride + i] > 0.0f;
+    tq_pixel_assemble_one_offset<K, BWD>(a, A, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
+  }
+  if (live) tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cx, cy, (float)npix, S_v, bad);
+}
+
+// =============================================================================================
+// Packed-math variant of the lane-per-unit kernel (single offset, P in {14, 20}).
+//
+// Measured on MI355X (profiles/r01_pmc_*): a wave64 VALU instruction holds its SIMD for 4 cycles
+// and instructions of different waves do not overlap, so these kernels are bound by the NUMBER of
+// VALU instructions; the FP32 peak of the chip is only reachable with the packed v_pk_{fma,mul,add}_f32
+// forms (two FP32 operations per lane per instruction).  Here every lane carries TWO horizontally
+// adjacent pixels of its unit in float2 registers, so all the per-pixel algebra issues as packed
+// instructions; only the transcendentals (exp2 for the x-factor, rcp and log2 per combination) are
+// per element.  The loop body covers R rows (R = 2 for P = 14, 1 for P = 20) so that every pixel
+// coordinate and every position in the float4 stream is a compile-time constant; the float4 holding a
+// group of 4 pixels is re-loaded, right after its last use, with the same group of the next body
+// (one body = 28 or 20 pixels of latency cover, G float4 registers).
+// =============================================================================================
+typedef float tq_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tq_f2 tq2(float a) { return (tq_f2){a, a}; }
+__device__ __forceinline__ tq_f2 tq2_rcp(tq_f2 a) { return (tq_f2){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ tq_f2 tq2_log2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)}; }
+__device__ __forceinline__ tq_f2 tq2_exp2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+
+template <int K>
+struct TqPixAcc2 {
+  tq_f2 ll[1 << K], sl[1 << K], sS[1 << K];
+  tq_f2 acc_b;
+  tq_f2 S0[K], Sx[K], Sy[K], Sr[K], SN[K];
+};
+
+// one pair of horizontally adjacent pixels (columns ic, ic+1 of row fj), single offset, alpha >= TQ_FAST_ALPHA (two Binet terms)
+template <int K, bool BWD>
+__device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K>& A, tq_f2 v, float b, const tq_f2* spot, const float* W,
+                                              tq_f2 fic, float fj, tq_f2 r2, float g) {
+  constexpr int M = 1 << K;
+  tq_f2 da[M];
+#pragma unroll
+  for (int mi = 1; mi < M; ++mi) {
+    tq_f2 mu = tq2(b);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if ((mi >> k) & 1) mu += spot[k];
+    const tq_f2 rmu = tq2_rcp(mu);
+    const tq_f2 ra = g * rmu;
+    const tq_f2 l2 = tq2_log2(v * rmu);
+    const tq_f2 rr = ra * ra;
+    A.ll[mi] += mu * l2;
+    A.sl[mi] += l2;
+    A.sS[mi] += ra * (1.0f / 12.0f - rr * (1.0f / 360.0f));
+    if (BWD) da[mi] = l2 * TQ_LN2 + (0.5f * ra + rr * (1.0f / 12.0f - rr * (1.0f / 120.0f)));
+  }
+  if (BWD) {
+    tq_f2 q[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = tq2(0.0f);
+#pragma unroll
+    for (int mi = 1; mi < M; ++mi) {
+      const tq_f2 cw = W[mi] * da[mi];
+      A.acc_b += cw;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if ((mi >> k) & 1) q[k] += cw;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const tq_f2 aq = q[k] * spot[k];
+      A.S0[k] += aq;
+      A.Sx[k] += aq * fic;
+      A.Sy[k] += aq * fj;
+      A.Sr[k] += aq * r2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) A.SN[k] += spot[k];
+}
+
+template <int K, int P, bool BWD>
+__global__ __launch_bounds__(256) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
+  static_assert(P % 2 == 0 && (P * P) % 4 == 0, "packed kernel needs an even tile side");
+  constexpr int M = 1 << K;
+  constexpr int R = ((P / 2) % 2) ? 2 : 1;  // rows per loop body so that the body starts on a float4 boundary
+  constexpr int G = R * P / 4;              // float4 groups per body
+  constexpr int NB = P / R;                 // bodies per tile
+  constexpr int npix = P * P, npix4 = npix / 4;
+  const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i_raw < B;
+  const int64_t i = live ? i_raw : (B - 1);
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i_raw >> 6) * npix4) * 64 + (i_raw & 63);
+
+  const float g = a.gain[0];
+  const float rg = TQ_FRCP(g);
+  const float ln_g = TQ_FLOG(g);
+  const float off0 = a.offset_samples[0];
+  const float tx = a.xy[2 * i], ty = a.xy[2 * i + 1];
+  const float b = a.background[i];
+  float amph[K], nl2[K], cx[K], cy[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float hk = a.height[k * B + i], wk = a.width[k * B + i];
+    cx[k] = a.x[k * B + i] + tx;
+    cy[k] = a.y[k * B + i] + ty;
+    const float inv2v = 0.5f * TQ_FRCP(wk * wk);
+    amph[k] = hk * inv2v * (1.0f / TQ_PI);
+    nl2[k] = -inv2v * 1.44269504088896340736f;
+  }
+  float W[M];
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) W[mi] = 0.0f;
+  if (BWD) tq_load_weights<K>(a, B, i, i, (int)((uint32_t)i / (uint32_t)(a.F * a.C)), W);
+
+  TqPixAcc<K> S;
+  tq_acc_zero<K>(S);
+  if (__all(b * rg >= TQ_FAST_ALPHA)) {
+    TqPixAcc2<K> A;
+  #pragma unroll
+    for (int mi = 0; mi < M; ++mi) A.ll[mi] = A.sl[mi] = A.sS[mi] = tq2(0.0f);
+    A.acc_b = tq2(0.0f);
+  #pragma unroll
+    for (int k = 0; k < K; ++k) A.S0[k] = A.Sx[k] = A.Sy[k] = A.Sr[k] = A.SN[k] = tq2(0.0f);
+
+    float4 ring[G];
+  #pragma unroll
+    for (int j = 0; j < G; ++j) ring[j] = src[j * 64];
+    for (int body = 0; body < NB; ++body) {
+      const float4* nxt = src + (int64_t)(body + 1) * G * 64;
+      const bool more = body + 1 < NB;
+  #pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const float fj = (float)(body * R + rr);
+        float agy[K];
+  #pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float dy = fj - cy[k];
+          agy[k] = amph[k] * __builtin_amdgcn_exp2f(dy * dy * nl2[k]);
+        }
+        const float fj2 = fj * fj;
+  #pragma unroll
+        for (int ip = 0; ip < P / 2; ++ip) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int pair = rr * (P / 2) + ip;  // pair index within the body (compile-time after unrolling)
+          const int gi = pair >> 1;            // float4 group within the body
+          const float4 d4 = ring[gi];
+          const tq_f2 D = (pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y};
+          if ((pair & 1) && more) ring[gi] = nxt[gi * 64];  // group consumed: fetch the next body's
+          const tq_f2 fic = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)};
+          const tq_f2 r2 = fic * fic + fj2;
+          tq_f2 spot[K];
+  #pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const tq_f2 dx = fic - cx[k];
+            spot[k] = agy[k] * tq2_exp2(dx * dx * nl2[k]);
+          }
+          tq_pixel_pair<K, BWD>(A, D - off0, b, spot, W, fic, fj, r2, g);
+        }
+      }
+    }
+
+    // fold the two pixel slots, then the common single-offset assembly / store
+  #pragma unroll
+    for (int mi = 1; mi < M; ++mi) {
+      S.ll[mi] = A.ll[mi].x + A.ll[mi].y;
+      S.sl[mi] = A.sl[mi].x + A.sl[mi].y;
+      S.sS[mi] = A.sS[mi].x + A.sS[mi].y;
+    }
+    S.acc_b = A.acc_b.x + A.acc_b.y;
+  #pragma unroll
+    for (int k = 0; k < K; ++k) {
+      S.S0[k] = A.S0[k].x + A.S0[k].y;
+      S.Sx[k] = A.Sx[k].x + A.Sx[k].y;
+      S.Sy[k] = A.Sy[k].x + A.Sy[k].y;
+      S.Sr[k] = A.Sr[k].x + A.Sr[k].y;
+      S.SN[k] = A.SN[k].x + A.SN[k].y;
+    }
+  } else {
+    // some unit of this wave has a small alpha = background / gain: general (scalar, exact Binet) loop
+    tq_il_pixel_loop<K, true, BWD, false>(S, a, src, P, npix, b, amph, nl2, cx, cy, g, rg, ln_g, W);
+  }
+  const float S_v = a.pixstats[i];
+  const float S_lv = a.pixstats[a.stats_stride + i];
+  const bool bad = a.pixstats[2 * a.stats_stride + i] > 0.0f;
+  tq_pixel_assemble_one_offset<K, BWD>(a, S, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
+  if (live) {
+    float hk[K], wk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      hk[k] = a.height[k * B + i];
+      wk[k] = a.width[k * B + i];
+    }
+    tq_pixel_store<K, true, BWD>(a, B, i, S, W, b, rg, hk, wk, cx, cy, (float)npix, S_v, bad);
+  }
+}
+
+// (U, npix) row-major tiles -> the interleaved layout above; out holds ceil(U/64) * npix4 * 256 floats
+__global__ __launch_bounds__(256) void tq_interleave_kernel(const float* __restrict__ images, float* __restrict__ out,
+                                                            const int64_t U, const int npix, const int64_t total4) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of the output
+  if (t >= total4) return;
+  const int npix4 = (npix + 3) >> 2;
+  const int lane = (int)(t & 63);
+  const int64_t rowq = t >> 6;
+  const int q = (int)(rowq % npix4);
+  const int64_t u = (rowq / npix4) * 64 + lane;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (u < U) {
+    const float* tile = images + u * npix;
+    const int p = 4 * q;
+    v.x = p < npix ? tile[p] : 0.f;
+    v.y = p + 1 < npix ? tile[p + 1] : 0.f;
+    v.z = p + 2 < npix ? tile[p + 2] : 0.f;
+    v.w = p + 3 < npix ? tile[p + 3] : 0.f;
+  }
+  reinterpret_cast<float4*>(out)[t] = v;
+}
+
+// Per-unit data statistics of the single-offset path: [0][u] = sum (D - delta), [1][u] = sum ln(D - delta),
+// [2][u] = number of pixels with D <= delta.  One wave per unit, sums in double.
+__global__ __launch_bounds__(256) void tq_image_stats_kernel(const float* __restrict__ images, const float* offset,
+                                                             float* __restrict__ out, const int64_t U, const int npix) {
+  const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (u >= U) return;
+  const float off = offset[0];
+  double sv = 0.0, slv = 0.0;
+  float nbad = 0.0f;
+  for (int p = lane; p < npix; p += 64) {
+    const float v = images[u * npix + p] - off;
+    if (v > 0.0f) {
+      sv += v;
+      slv += log((double)v);
+    } else {
+      nbad += 1.0f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sv += __shfl_down(sv, o, 64);
+    slv += __shfl_down(slv, o, 64);
+    nbad += __shfl_down(nbad, o, 64);
+  }
+  if (lane == 0) {
+    out[u] = (float)sv;
+    out[U + u] = (float)slv;
+    out[2 * U + u] = nbad;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
 extern "C" const char* tq_last_error(void) { return g_err; }
-extern "C" int tq_version(void) { return 100; }
+extern "C" int tq_version(void) { return 101; }
 void tq_set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
-template <int K>
-static int launch_k(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
-  const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK)), block(TQ_BLOCK);
-  const bool bwd = a.g_background != nullptr;
-  const bool one = a.O == 1;
-  const size_t lds = sizeof(float) * TQ_UNITS_PER_BLOCK * (tq_tile_stride(a.P * a.P) + 2 * K * TQ_MAX_P);
-  if (one && bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, true, true>), grid, block, lds, st, a, B);
-  else if (one) hipLaunchKernelGGL((tq_ksmogn_kernel<K, true, false>), grid, block, lds, st, a, B);
-  else if (bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, true>), grid, block, lds, st, a, B);
-  else hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, false>), grid, block, lds, st, a, B);
+static int launch_status(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    tq_set_error(hipGetErrorString(e));
+    char buf[200];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    tq_set_error(buf);
     return TQ_ERR_LAUNCH;
   }
   return TQ_OK;
 }
 
+template <int K, bool ONE>
+static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
+  const bool bwd = a.g_background != nullptr;
+  // contiguous batch + interleaved copy available + enough units to fill the chip with 64-unit waves
+  if (a.images_il && !a.ndx && !a.fdx && a.nb == a.nb_full && a.fb == a.F && B >= a.il_min_units) {
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    if (ONE && (a.P == 14 || a.P == 20)) {
+      if (a.P == 14) {
+        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, true>), grid, block, 0, st, a, B);
+        else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, false>), grid, block, 0, st, a, B);
+      } else {
+        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, true>), grid, block, 0, st, a, B);
+        else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, false>), grid, block, 0, st, a, B);
+      }
+      return launch_status("tq_ksmogn_il2_kernel");
+    }
+    if (bwd) hipLaunchKernelGGL((tq_ksmogn_il_kernel<K, ONE, true>), grid, block, 0, st, a, B);
+    else hipLaunchKernelGGL((tq_ksmogn_il_kernel<K, ONE, false>), grid, block, 0, st, a, B);
+    return launch_status("tq_ksmogn_il_kernel");
+  }
+  if (!a.images) {
+    tq_set_error("tq_ksmogn_log_prob: images is NULL and the interleaved kernel does not apply to this batch");
+    return TQ_ERR_ARG;
+  }
+  const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK)), block(TQ_BLOCK);
+  const size_t lds = sizeof(float) * TQ_UNITS_PER_BLOCK * (tq_tile_stride(a.P * a.P) + 2 * K * TQ_MAX_P);
+  if (bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, ONE, true>), grid, block, lds, st, a, B);
+  else hipLaunchKernelGGL((tq_ksmogn_kernel<K, ONE, false>), grid, block, lds, st, a, B);
+  return launch_status("tq_ksmogn_kernel");
+}
+
+template <int K>
+static int launch_k(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
+  // the single-offset formulation needs the per-unit data statistics; without them the general
+  // (online log-sum-exp) path handles O == 1 as well
+  if (a.O == 1 && a.pixstats) return launch_kb<K, true>(a, B, st);
+  return launch_kb<K, false>(a, B, st);
+}
+
 extern "C" int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream) {
-  if (!a || !a->images || !a->xy || !a->background || !a->height || !a->width || !a->x || !a->y || !a->gain ||
-      !a->offset_samples || !a->offset_logits || !a->ll) {
+  if (!a || (!a->images && !a->images_il) || !a->xy || !a->background || !a->height || !a->width || !a->x || !a->y ||
+      !a->gain || !a->offset_samples || !a->offset_logits || !a->ll) {
     tq_set_error("tq_ksmogn_log_prob: NULL required pointer");
     return TQ_ERR_ARG;
   }
@@ -438,4 +846,32 @@ extern "C" int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream) {
     case 3: return launch_k<3>(*a, B, st);
     default: return launch_k<4>(*a, B, st);
   }
+}
+
+extern "C" int64_t tq_interleaved_floats(int64_t U, int32_t P) {
+  const int64_t npix4 = ((int64_t)P * P + 3) / 4;
+  return ((U + 63) / 64) * npix4 * 256;
+}
+
+extern "C" int tq_images_interleave(const float* images, float* images_il, int64_t U, int32_t P, void* stream) {
+  if (!images || !images_il || U < 1 || P < 2 || P > TQ_MAX_P) {
+    tq_set_error("tq_images_interleave: bad argument");
+    return TQ_ERR_ARG;
+  }
+  const int64_t total4 = tq_interleaved_floats(U, P) / 4;
+  hipLaunchKernelGGL(tq_interleave_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     images, images_il, U, P * P, total4);
+  return launch_status("tq_interleave_kernel");
+}
+
+extern "C" int tq_image_stats(const float* images, const float* offset, float* pixstats, int64_t U, int32_t P,
+                              void* stream) {
+  if (!images || !offset || !pixstats || U < 1 || P < 2 || P > TQ_MAX_P) {
+    tq_set_error("tq_image_stats: bad argument");
+    return TQ_ERR_ARG;
+  }
+  const int64_t threads = U * 64;
+  hipLaunchKernelGGL(tq_image_stats_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     images, offset, pixstats, U, P * P);
+  return launch_status("tq_image_stats_kernel");
 }

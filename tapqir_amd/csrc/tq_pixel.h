@@ -31,60 +31,60 @@ TQ_HD void tq_combo_prepare(float mu, float rg, float g, float ln_g, TqComboPix*
   c->ralpha = g * c->rmu;
 }
 
-// Single-offset fast path (all offset samples identical after host-side merging).
-//   v = D - delta (> 0), lv = ln v.  The combination-independent part of the log-density,
-//   ln w - ln v - ln sqrt(2 pi), is added once per pixel by the caller; the rest is split as
-//     log p = (1/g) * [mu phi(v/mu)]  +  [ (1/2) ln alpha - S(alpha) ]
-//   so that the caller accumulates sum mu*phi and applies 1/g once per unit.
-//   Outputs: mphi = mu*phi, rest = (1/2) ln alpha - S(alpha), da = d log p / d alpha.
-// The gain term needs no per-combination work here: with one offset,
-//   alpha (da + 1) - v/g = (mu da + mu - v) / g, and the pixel sums of mu*da, mu and v are
-//   linear in sums the kernel accumulates anyway (see tq_ksmogn.hip).
-// FAST: the caller guarantees alpha >= TQ_FAST_ALPHA (alpha >= background / gain for every
-// combination); S = 1/(12a), S' = -1/(12a^2) are then exact to 7e-7 / 2e-7 absolute per pixel.
-#define TQ_FAST_ALPHA 16.0f
+// ---- single-offset path (all offset samples identical after host-side merging) -------------------
+// With one offset delta, v = D - delta is a property of the DATA.  Write the per-pixel log-density as
+//   log p = [ln w - ln sqrt(2pi) - ln v] + (1/g) [mu ln(v/mu) + mu - v] + (1/2) [ln v - ln g - ln(v/mu)] - S(alpha)
+// Summed over the pixels of a unit, everything except  sum mu*ln(v/mu),  sum ln(v/mu),  sum S(alpha)  and
+// sum mu  is a function of the per-unit data statistics
+//   S_v = sum_pix v ,   S_lv = sum_pix ln v        (tq_image_stats, computed once per dataset)
+// so the pixel loop evaluates, per combination with at least one spot,
+//   rcp(mu), l2 = log2(v/mu), r = g/mu             -> running sums of mu*l2, l2, S
+//   da = d log p / d alpha = ln2*l2 + r/2 - S'(alpha)
+// and NOTHING for the spot-free combination (mu = background for every pixel):
+//   sum mu*ln(v/mu) = b (S_lv - n ln b),  sum ln(v/mu) = S_lv - n ln b,  sum_pix da = S_lv - n ln b + n c_da.
+// The gain term alpha (da + 1) - v/g = (mu da + mu - v)/g is linear in sums the kernel has anyway.
+// FAST: the caller guarantees alpha >= TQ_FAST_ALPHA for every combination (alpha >= background /
+// gain); two Binet terms, S = 1/(12a) - 1/(360a^3), S' = -1/(12a^2) + 1/(120a^4), are then exact to
+// 2.4e-8 / 1.5e-8 absolute per pixel.  (8 rather than a larger cut: typical data has background/gain
+// around 20 with +-30 % spread across draws, and one unit below the cut sends its whole wave to the
+// general loop.)
+#define TQ_FAST_ALPHA 8.0f
 template <bool FAST>
-TQ_HD void tq_pix_one_offset(float v, float lv_minus_lng, float mu, float rg, float g, float* mphi, float* rest,
-                             float* da) {
+TQ_HD void tq_pix_one_offset(float v, float mu, float g, float rg, float ln_g, float* l2, float* S, float* da) {
   const float rmu = TQ_FRCP(mu);
-  const float rho = v * rmu;
-  const float lrho = TQ_FLOG(rho);
-  *mphi = mu * ((lrho + 1.0f) - rho);
   const float ralpha = g * rmu;
-  const float lnalpha = lv_minus_lng - lrho;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float lg2 = __builtin_amdgcn_logf(v * rmu);
+#else
+  const float lg2 = log2f(v * rmu);
+#endif
+  *l2 = lg2;
   if (FAST) {
-    *rest = 0.5f * lnalpha - ralpha * (1.0f / 12.0f);
-    *da = lrho + ralpha * (0.5f + ralpha * (1.0f / 12.0f));
+    const float r2 = ralpha * ralpha;
+    *S = ralpha * (1.0f / 12.0f - r2 * (1.0f / 360.0f));
+    *da = lg2 * TQ_LN2 + (0.5f * ralpha + r2 * (1.0f / 12.0f - r2 * (1.0f / 120.0f)));
   } else {
-    float S, dS;
-    tq_binet(mu * rg, lnalpha, ralpha, &S, &dS);
-    *rest = 0.5f * lnalpha - S;
-    *da = lrho + (0.5f * ralpha - dS);
+    float S_, dS_;
+    tq_binet(mu * rg, TQ_FLOG(mu) - ln_g, ralpha, &S_, &dS_);
+    *S = S_;
+    *da = lg2 * TQ_LN2 + (0.5f * ralpha - dS_);
   }
 }
 
-// The all-spots-absent combination has mu = background for every pixel of a unit, so its
-// alpha-dependent terms are per-unit constants (single-offset path only).
+// per-unit constants of the spot-free combination
 struct TqCombo0 {
-  float alpha, lnb, rb;  // b/g, ln b, 1/b
-  float c_lp;            // (1/2) ln alpha - S(alpha)
-  float c_da;            // 1/(2 alpha) - S'(alpha)
+  float alpha, lnb;  // b/g, ln b
+  float S;           // S(alpha)
+  float c_da;        // 1/(2 alpha) - S'(alpha)
 };
 TQ_HD void tq_combo0_prepare(float b, float rg, float g, float ln_g, TqCombo0* c) {
   c->alpha = b * rg;
   c->lnb = TQ_FLOG(b);
-  c->rb = TQ_FRCP(b);
-  const float lna = c->lnb - ln_g, ra = g * c->rb;
+  const float lna = c->lnb - ln_g, ra = g * TQ_FRCP(b);
   float S, dS;
   tq_binet(c->alpha, lna, ra, &S, &dS);
-  c->c_lp = 0.5f * lna - S;
+  c->S = S;
   c->c_da = 0.5f * ra - dS;
-}
-// (per pixel only phi is needed: sum_pix [alpha phi + c_lp] = alpha * sum phi + npix * c_lp)
-TQ_HD void tq_pix_combo0(const TqCombo0& c, float v, float lv, float* phi, float* da) {
-  const float lrho = lv - c.lnb;
-  *phi = (lrho + 1.0f) - v * c.rb;
-  *da = lrho + c.c_da;
 }
 
 // Online log-sum-exp accumulator over offsets for one combination.

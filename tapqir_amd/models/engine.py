@@ -62,9 +62,31 @@ class CosmosEngine:
         self.xy = data.xy.to(dev, f32).contiguous()
         self.is_ontarget = data.is_ontarget.to(dev, torch.uint8).contiguous()
         self.mask = data.mask.to(dev, torch.uint8).contiguous()
+        # tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the
+        # library so that any C caller gets the same layout
+        self.images_il = None
+        if not self._hostcheck:
+            U = self.Nt * self.F * self.C
+            n_il = int(lib.tq_interleaved_floats(U, self.P))
+            self.images_il = torch.empty(n_il, dtype=f32, device=dev)
+            _lib.check(lib.tq_images_interleave(_lib.ptr(self.images), _lib.ptr(self.images_il), U, self.P,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "tq_images_interleave")
         off_s, off_l = merge_offsets(data.offset.samples, data.offset.weights)
         self.offset_samples, self.offset_logits = off_s.to(dev), off_l.to(dev)
         self.O = int(off_s.numel())
+        # per-unit data statistics of the single-offset formulation (sum v, sum ln v, #masked pixels)
+        self.pixstats = None
+        if self.O == 1:
+            U = self.Nt * self.F * self.C
+            self.pixstats = torch.empty(3 * U, dtype=f32, device=dev)
+            if self._hostcheck:
+                lib.hc_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples), _lib.ptr(self.pixstats),
+                                   C.c_int64(U), C.c_int32(self.P))
+            else:
+                _lib.check(lib.tq_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples),
+                                              _lib.ptr(self.pixstats), U, self.P,
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tq_image_stats")
         self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps)
         n = self.layout.total
         self.params = torch.zeros(n, dtype=f32, device=dev)
@@ -81,6 +103,9 @@ class CosmosEngine:
         self._ws_key = None
         self.adam_step = 0
         self.lr, self.betas, self.adam_eps = 0.005, (0.9, 0.999), 1e-8
+        # contiguous batches at least this large use the lane-per-unit pixel kernel (64 units per wave):
+        # 65536 units = one wave per SIMD of an MI355X
+        self.il_min_units = 65536
 
     # -- workspace ---------------------------------------------------------------------------------
     def _workspace(self, nb, fb):
@@ -110,12 +135,15 @@ class CosmosEngine:
         p = _lib.ptr
         a = _lib.CosmosArgs()
         a.images, a.xy, a.is_ontarget, a.aoi_mask = p(self.images), p(self.xy), p(self.is_ontarget), p(self.mask)
+        a.images_il = p(self.images_il)
+        a.pixstats = p(self.pixstats)
         a.ndx, a.fdx = p(ndx), p(fdx)
         a.offset_samples, a.offset_logits = p(self.offset_samples), p(self.offset_logits)
         a.params, a.grad, a.exp_avg, a.exp_avg_sq = p(self.params), p(self.grad), p(self.exp_avg), p(self.exp_avg_sq)
         a.lat, a.pix, a.aoi_part, a.blk_part = p(self.lat), p(self.pix), p(self.aoi_part), p(self.blk_part)
         a.site = p(self.site)
         a.draw_locals = int(bool(draw_globals if draw_locals is None else draw_locals))
+        a.il_min_units = self.il_min_units
         a.gsum, a.globals, a.gbase, a.elbo_out = p(self._gsum_buf), p(self.globals), p(self.gbase), p(self.elbo_out)
         a.Nt, a.F, a.C, a.P, a.K, a.O = self.Nt, self.F, self.C, self.P, self.K, self.O
         a.nb, a.fb, a.n_offset, a.draw_globals = nb, fb, self.n_offset, int(bool(draw_globals))

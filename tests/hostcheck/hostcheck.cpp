@@ -49,15 +49,15 @@ void hc_mean_frac(double lam, int K, double* val, double* dval) { tq_mean_frac(l
 
 }  // extern "C"
 
-// Host emulation of tq_ksmogn_kernel (same per-pixel functions and the same algebra for the
-// moments and the gain term; plain loops, double accumulators).
+// Host emulation of the pixel kernels (same per-pixel functions and the same algebra for the
+// single-offset assembly, the moments and the gain term; plain loops, double accumulators).
 template <int K>
 static void ksmogn_host(const tq_ksmogn_args& a) {
   constexpr int M = 1 << K;
   const int64_t B = (int64_t)a.nb * a.fb * a.C;
   const int P = a.P, npix = P * P;
   const bool bwd = a.g_background != nullptr;
-  const bool one = a.O == 1;
+  const bool one = a.O == 1 && a.pixstats != nullptr;
   const float g = a.gain[0], rg = 1.0f / g, ln_g = logf(g);
   for (int64_t i = 0; i < B; ++i) {
     const int c = (int)(i % a.C);
@@ -93,10 +93,15 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
       }
     }
     const bool fast = b * rg >= TQ_FAST_ALPHA;  // device: wave-uniform __all() of the same test
-    TqCombo0 c0;
-    tq_combo0_prepare(b, rg, g, ln_g, &c0);
-    double ll[M] = {0}, base = 0, acc_b = 0, acc_g = 0, sv = 0, cnt = 0;
+    double ll[M] = {0}, sl[M] = {0}, sS[M] = {0}, acc_b = 0, acc_g = 0;
     double S0[K] = {0}, Sx[K] = {0}, Sy[K] = {0}, Sr[K] = {0}, SN[K] = {0};
+    bool bad = false;
+    float S_v = 0, S_lv = 0;
+    if (one) {
+      S_v = a.pixstats[u];
+      S_lv = a.pixstats[a.stats_stride + u];
+      bad = a.pixstats[2 * a.stats_stride + u] > 0.0f;
+    }
     for (int pix = 0; pix < npix; ++pix) {
       const int j = pix / P, ic = pix % P;
       const float D = a.images[u * npix + pix];
@@ -106,35 +111,24 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
         const float dx = fic - cx[k], dy = fj - cy[k];
         spot[k] = amph[k] * expf(-dx * dx * inv2v[k]) * expf(-dy * dy * inv2v[k]);
       }
-      float lp[M], da[M], gq[M];
-      bool valid = true;
+      float da[M], gq[M];
+      for (int mi = 0; mi < M; ++mi) { da[mi] = 0; gq[mi] = 0; }
       if (one) {
-        const float v = D - a.offset_samples[0];
-        valid = v > 0.0f;
-        if (valid) {
-          const float lv = logf(v);
-          base += (a.offset_logits[0] - TQ_LN_SQRT_2PI) - lv;
-          float phi0;
-          tq_pix_combo0(c0, v, lv, &phi0, &da[0]);
-          lp[0] = c0.alpha * phi0 + c0.c_lp;
-          for (int mi = 1; mi < M; ++mi) {
-            float mu = b, mphi, rest;
-            for (int k = 0; k < K; ++k)
-              if ((mi >> k) & 1) mu += spot[k];
-            if (fast) tq_pix_one_offset<true>(v, lv - ln_g, mu, rg, g, &mphi, &rest, &da[mi]);
-            else tq_pix_one_offset<false>(v, lv - ln_g, mu, rg, g, &mphi, &rest, &da[mi]);
-            lp[mi] = rg * mphi + rest;
-          }
-          sv += v;
-          cnt += 1;
-          for (int k = 0; k < K; ++k) SN[k] += spot[k];
-        } else {
-          for (int mi = 0; mi < M; ++mi) { lp[mi] = -INFINITY; da[mi] = 0; }
+        const float v = bad ? fmaxf(D - a.offset_samples[0], 1.0f) : D - a.offset_samples[0];
+        for (int mi = 1; mi < M; ++mi) {
+          float mu = b, l2, S;
+          for (int k = 0; k < K; ++k)
+            if ((mi >> k) & 1) mu += spot[k];
+          if (fast) tq_pix_one_offset<true>(v, mu, g, rg, ln_g, &l2, &S, &da[mi]);
+          else tq_pix_one_offset<false>(v, mu, g, rg, ln_g, &l2, &S, &da[mi]);
+          ll[mi] += (double)mu * l2;
+          sl[mi] += l2;
+          sS[mi] += S;
         }
-        for (int mi = 0; mi < M; ++mi) gq[mi] = 0;
+        for (int k = 0; k < K; ++k) SN[k] += spot[k];
       } else {
         for (int mi = 0; mi < M; ++mi) {
-          float mu = b;
+          float mu = b, lp;
           for (int k = 0; k < K; ++k)
             if ((mi >> k) & 1) mu += spot[k];
           TqComboPix cp;
@@ -148,15 +142,15 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
               tq_lse_push(&acc, cp, v, lv, a.offset_logits[o] - lv);
             }
           }
-          if (fast) tq_lse_finish<true>(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
-          else tq_lse_finish<false>(acc, cp, rg, &lp[mi], &da[mi], &gq[mi]);
+          if (fast) tq_lse_finish<true>(acc, cp, rg, &lp, &da[mi], &gq[mi]);
+          else tq_lse_finish<false>(acc, cp, rg, &lp, &da[mi], &gq[mi]);
+          ll[mi] += lp;
         }
       }
-      for (int mi = 0; mi < M; ++mi) ll[mi] += lp[mi];
-      if (bwd && valid) {
+      if (bwd) {
         float q[K];
         for (int k = 0; k < K; ++k) q[k] = 0;
-        for (int mi = 0; mi < M; ++mi) {
+        for (int mi = one ? 1 : 0; mi < M; ++mi) {
           const float cw = W[mi] * da[mi];
           acc_b += cw;
           acc_g += W[mi] * gq[mi];
@@ -173,9 +167,25 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
         }
       }
     }
-    for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = (float)(ll[mi] + (one ? base : 0.0));
+    const double fn = npix;
+    if (one) {  // tq_pixel_assemble_one_offset
+      TqCombo0 c0;
+      tq_combo0_prepare(b, rg, g, ln_g, &c0);
+      const double lw0 = a.offset_logits[0] - TQ_LN_SQRT_2PI;
+      const double common = lw0 * fn - S_lv, S_lvg = S_lv - fn * ln_g, sl0 = S_lv - fn * c0.lnb, mmv = b * fn - S_v;
+      ll[0] = common + rg * (b * sl0 + mmv) + 0.5 * (S_lvg - sl0) - fn * c0.S;
+      for (int mi = 1; mi < M; ++mi) {
+        double sn = 0;
+        for (int k = 0; k < K; ++k)
+          if ((mi >> k) & 1) sn += SN[k];
+        ll[mi] = common + rg * (TQ_LN2 * ll[mi] + mmv + sn) + 0.5 * (S_lvg - TQ_LN2 * sl[mi]) - sS[mi];
+      }
+      if (bwd) acc_b += W[0] * (sl0 + fn * c0.c_da);
+    }
+    for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = bad ? -INFINITY : (float)ll[mi];
     if (bwd) {
-      a.g_background[i] = (float)(acc_b * rg);
+      const double z = bad ? 0.0 : 1.0;
+      a.g_background[i] = (float)(z * acc_b * rg);
       if (one) {
         double Wsum = 0, mu_da = b * acc_b, mu_w = 0;
         for (int mi = 0; mi < M; ++mi) Wsum += W[mi];
@@ -186,19 +196,32 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
           mu_da += S0[k];
           mu_w += Wk * SN[k];
         }
-        acc_g = rg * (mu_da + mu_w + Wsum * (b * cnt - sv));
+        acc_g = rg * (mu_da + mu_w + Wsum * (b * fn - S_v));
       }
-      a.g_gain[i] = (float)(-acc_g * rg);
+      a.g_gain[i] = (float)(-z * acc_g * rg);
       for (int k = 0; k < K; ++k) {
         const double rw = 1.0 / wk[k];
         const double S1x = Sx[k] - cx[k] * S0[k], S1y = Sy[k] - cy[k] * S0[k];
         const double S2 = Sr[k] - 2.0 * (cx[k] * Sx[k] + cy[k] * Sy[k]) + ((double)cx[k] * cx[k] + (double)cy[k] * cy[k]) * S0[k];
-        a.g_height[k * B + i] = (float)(S0[k] * rg / hk[k]);
-        a.g_x[k * B + i] = (float)(rg * S1x * rw * rw);
-        a.g_y[k * B + i] = (float)(rg * S1y * rw * rw);
-        a.g_width[k * B + i] = (float)(rg * (S2 * rw * rw * rw - 2.0 * S0[k] * rw));
+        a.g_height[k * B + i] = (float)(z * S0[k] * rg / hk[k]);
+        a.g_x[k * B + i] = (float)(z * rg * S1x * rw * rw);
+        a.g_y[k * B + i] = (float)(z * rg * S1y * rw * rw);
+        a.g_width[k * B + i] = (float)(z * rg * (S2 * rw * rw * rw - 2.0 * S0[k] * rw));
       }
     }
+  }
+}
+
+extern "C" void hc_image_stats(const float* images, const float* offset, float* out, int64_t U, int32_t P) {
+  const int npix = P * P;
+  for (int64_t u = 0; u < U; ++u) {
+    double sv = 0, slv = 0;
+    float nbad = 0;
+    for (int p = 0; p < npix; ++p) {
+      const float v = images[u * npix + p] - offset[0];
+      if (v > 0.0f) { sv += v; slv += log((double)v); } else nbad += 1;
+    }
+    out[u] = (float)sv; out[U + u] = (float)slv; out[2 * U + u] = nbad;
   }
 }
 
@@ -245,7 +268,8 @@ void hc_cosmos_elbo_grads(const tq_cosmos_args* a) {
   const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
   tq_ksmogn_args k;
   memset(&k, 0, sizeof(k));
-  k.images = a->images; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
+  k.images = a->images; k.images_il = nullptr; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
+  k.pixstats = a->pixstats; k.stats_stride = U;
   k.background = a->lat;
   k.height = a->lat + (int64_t)1 * B;
   k.width = a->lat + (int64_t)(1 + K) * B;
