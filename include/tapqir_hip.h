@@ -170,6 +170,9 @@ typedef struct {
   float lr, beta1, beta2, adam_eps;
   float bias_correction1, bias_correction2;  /* 1 - beta^t for this step */
   int32_t zero_grad;           /* 1: Adam clears grad after use (minibatch mode keeps grad dense-zero) */
+  int32_t fuse_adam;           /* 1 (full batch only): tq_cosmos_elbo_grads applies Adam to the local parameters of
+                                  each unit right where their gradient is formed (no gradient round trip through
+                                  HBM) and tq_cosmos_adam then updates only the per-AOI and global tail */
   /* RNG */
   uint64_t seed;
   uint32_t step;
@@ -195,6 +198,32 @@ int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream);
 int tq_cosmos_adam(const tq_cosmos_args* a, void* stream);
 /* all of the above back to back */
 int tq_cosmos_step(const tq_cosmos_args* a, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------
+ * Posterior read-out: Monte-Carlo estimate (`particles` joint guide draws) of p(z | .) and p(theta = k | .).
+ * Replaces cosmos.compute_probs (tapqir/models/cosmos.py:609-672): for every particle the
+ * global latents (pi, lamda, proximity) and the spot positions x_k, y_k are drawn from the guide,
+ * r(z, theta | m) = softmax_{z,theta}[log p(z) p(theta|z) prod_k p(m_k|theta) (p(x_k|theta) p(y_k|theta))^{m_k}],
+ * R(z, theta) = sum_m prod_k q(m_k) r(z, theta | m);  z_probs = mean_particles sum_theta R,
+ * theta_probs[k] = mean_particles R(z=1, theta=k+1).  Off-target AOIs are left at zero, as in the reference.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* params;         /* flat unconstrained parameters (layout of tq_cosmos_args) */
+  const uint8_t* is_ontarget;  /* [Nt] */
+  void* globals_p;             /* [particles] TqGlobals (tq_globals_size() bytes each), workspace */
+  void* gbase_p;               /* [particles] TqGlobalBase (tq_gbase_size() bytes each); input when draw == 0 */
+  const float* xy_given;       /* [particles][2K][U] spot positions (x_0..x_{K-1}, y_0..y_{K-1}) when draw == 0, else NULL */
+  float* z_probs;              /* (Nt, F, Q, 2) out */
+  float* theta_probs;          /* (K, Nt, F, Q) out */
+  int32_t Nt, F, C, P, K;
+  int32_t particles;
+  int32_t draw;                /* 1: draw latents from the guide; 0: use gbase_p / xy_given (parity tests) */
+  float eps;
+  uint64_t seed;
+} tq_probs_args;
+
+int tq_cosmos_probs(const tq_probs_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/prof
-timeout -k 10 400 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $R/gpurun_out/pytest_gpu.log 2>&1
+timeout -k 10 400 python -m pytest tests -m gpu -q -p no:cacheprovider > $R/gpurun_out/pytest_gpu.log 2>&1
 rc=$?; echo "pytest rc=$rc"; tail -4 $R/gpurun_out/pytest_gpu.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 99; fi
 cd /tmp && export TMPDIR=/tmp

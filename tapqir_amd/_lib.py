@@ -60,8 +60,19 @@ class CosmosArgs(C.Structure):
         ("gain_std", C.c_float), ("lamda_rate", C.c_float), ("proximity_rate", C.c_float),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("bias_correction1", C.c_float), ("bias_correction2", C.c_float),
-        ("zero_grad", C.c_int32),
+        ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32),
         ("seed", C.c_uint64), ("step", C.c_uint32),
+    ]
+
+
+class ProbsArgs(C.Structure):
+    """``tq_probs_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("params", C.c_void_p), ("is_ontarget", C.c_void_p), ("globals_p", C.c_void_p), ("gbase_p", C.c_void_p),
+        ("xy_given", C.c_void_p), ("z_probs", C.c_void_p), ("theta_probs", C.c_void_p),
+        ("Nt", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("K", C.c_int32),
+        ("particles", C.c_int32), ("draw", C.c_int32), ("eps", C.c_float), ("seed", C.c_uint64),
     ]
 
 
@@ -70,7 +81,7 @@ EXPORTS = [
     "tq_version", "tq_last_error", "tq_ksmogn_log_prob", "tq_interleaved_floats", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step",
+    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_probs",
 ]
 
 _lib = None
@@ -111,6 +122,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int
+    lib.tq_cosmos_probs.argtypes = [C.POINTER(ProbsArgs), C.c_void_p]
+    lib.tq_cosmos_probs.restype = C.c_int
     _lib = lib
     return lib
 

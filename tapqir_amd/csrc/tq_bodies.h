@@ -99,6 +99,8 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int64_t t) {
   for (int j = 0; j < TQ_NSITE_TERMS; ++j) a.site[(int64_t)j * NS + t] = terms[j];
 }
 
+TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO);
+
 // ---- per-unit ELBO terms and gradients --------------------------------------------------------------------
 // part[] receives this unit's contribution to the cross-unit sums (layout TQ_GS_*).
 template <int K>
@@ -162,8 +164,13 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
   TqUnitOut<K> out;
   tq_cosmos_unit<K>(in, G, C, &out);
 
+  if (a.fuse_adam) {
 #pragma unroll
-  for (int r = 0; r < NL; ++r) a.grad[(int64_t)r * U + ix.u] = masked ? 0.0f : out.g[r];
+    for (int r = 0; r < NL; ++r) tq_adam_apply(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < NL; ++r) a.grad[(int64_t)r * U + ix.u] = masked ? 0.0f : out.g[r];
+  }
   a.aoi_part[i] = masked ? 0.0f : out.g_bml;
   a.aoi_part[B + i] = masked ? 0.0f : out.g_bsl;
 
@@ -203,13 +210,92 @@ TQ_HD double tq_body_globals_grad(const tq_cosmos_args& a, int s) {
 }
 
 // ---- Adam on one element (torch.optim.Adam, no amsgrad / weight decay; minimises -ELBO) ------------------
-TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
-  const float g = -a.grad[j];
+// p = current parameter value, dELBO = d ELBO / d param
+TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO) {
+  const float g = -dELBO;
   const float m = a.beta1 * a.exp_avg[j] + (1.0f - a.beta1) * g;
   const float v = a.beta2 * a.exp_avg_sq[j] + (1.0f - a.beta2) * g * g;
   a.exp_avg[j] = m;
   a.exp_avg_sq[j] = v;
   const float denom = sqrtf(v) / sqrtf(a.bias_correction2) + a.adam_eps;
-  a.params[j] -= (a.lr / a.bias_correction1) * (m / denom);
+  a.params[j] = p - (a.lr / a.bias_correction1) * (m / denom);
+}
+TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
+  tq_adam_apply(a, j, a.params[j], a.grad[j]);
   if (a.zero_grad) a.grad[j] = 0.0f;
+}
+
+// ---- posterior read-out -----------------------------------------------------------------------------------
+TQ_HD void tq_body_probs_globals(const tq_probs_args& a, int s, int particle) {
+  TqGlobalConsts C;
+  C.K = a.K; C.P = a.P; C.Q = a.C; C.eps = a.eps;
+  C.gain_std = C.lamda_rate = C.proximity_rate = 1.0;  // priors are not used for draws
+  const int64_t U = (int64_t)a.Nt * a.F * a.C;
+  const float* ug = a.params + (int64_t)TQ_NLOCAL(a.K) * U + 2 * (int64_t)a.Nt * a.C;
+  TqGlobalSite p;
+  tq_globals_constrain_site(ug, C, s, &p);
+  tq_globals_sample_site(s, p, C, a.seed, 0x40000000u + (uint32_t)particle, a.draw,
+                         (TqGlobalBase*)a.gbase_p + particle, (TqGlobals*)a.globals_p + particle);
+}
+
+template <int K>
+TQ_HD void tq_body_probs_unit(const tq_probs_args& a, int64_t u) {
+  const int64_t U = (int64_t)a.Nt * a.F * a.C;
+  const int c = (int)(u % a.C);
+  const int n = (int)(u / ((int64_t)a.F * a.C));
+  float z1 = 0.0f, th[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) th[k] = 0.0f;
+  if (a.is_ontarget[n]) {  // cosmos.py:615-623: only on-target AOIs are evaluated
+    const float H = 0.5f * (a.P + 1);
+    float um[K], xm[K], ym[K], sz[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      um[k] = a.params[(int64_t)TQ_ROW(TQ_P_MPROBS, k, K) * U + u];
+      const float lo = -H + a.eps, hi = H - a.eps;
+      xm[k] = lo + (hi - lo) * tq_sigmoid(a.params[(int64_t)TQ_ROW(TQ_P_XMEAN, k, K) * U + u]);
+      ym[k] = lo + (hi - lo) * tq_sigmoid(a.params[(int64_t)TQ_ROW(TQ_P_YMEAN, k, K) * U + u]);
+      sz[k] = 2.0f + expf(a.params[(int64_t)TQ_ROW(TQ_P_SIZE, k, K) * U + u]);
+    }
+    for (int p = 0; p < a.particles; ++p) {
+      float x[K], y[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (a.draw) {
+#pragma nounroll
+          for (int ax = 0; ax < 2; ++ax) {
+            TqPhilox s;
+            tq_philox_init(&s, a.seed, 0x40000000u + (uint32_t)p, 0x800u + 2 * k + ax, (uint64_t)u);
+            const float mean = ax ? ym[k] : xm[k];
+            const float c1 = sz[k] * (mean + H) / (2.0f * H), c0 = sz[k] - c1;
+            const float g1 = tq_sample_std_gamma(&s, c1), g0 = tq_sample_std_gamma(&s, c0);
+            float tt = fminf(fmaxf(g1 / (g1 + g0), 1.17549435e-38f), 1.0f - 5.96046448e-08f);
+            const float v = fminf(fmaxf(-H + 2.0f * H * tt, -H + a.eps * 2.0f * H), H - a.eps * 2.0f * H);
+            if (ax) y[k] = v; else x[k] = v;
+          }
+        } else {
+          x[k] = a.xy_given[((int64_t)p * 2 * K + k) * U + u];
+          y[k] = a.xy_given[((int64_t)p * 2 * K + K + k) * U + u];
+        }
+      }
+      float R[K];
+      tq_zt_responsibilities<K>(x, y, um, ((const TqGlobals*)a.globals_p)[p], c, H, R);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        th[k] += R[k];
+        z1 += R[k];
+      }
+    }
+    const float inv = 1.0f / (float)a.particles;
+    z1 *= inv;
+#pragma unroll
+    for (int k = 0; k < K; ++k) th[k] *= inv;
+    a.z_probs[2 * u] = 1.0f - z1;
+    a.z_probs[2 * u + 1] = z1;
+  } else {
+    a.z_probs[2 * u] = 0.0f;
+    a.z_probs[2 * u + 1] = 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) a.theta_probs[(int64_t)k * U + u] = th[k];
 }

@@ -121,9 +121,44 @@ __global__ __launch_bounds__(64) void tq_elbo_finish_kernel(const tq_cosmos_args
   }
 }
 
-__global__ __launch_bounds__(256) void tq_adam_kernel(const tq_cosmos_args a, const int64_t total) {
+__global__ __launch_bounds__(256) void tq_adam_kernel(const tq_cosmos_args a, const int64_t first, const int64_t total) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) tq_body_adam(a, j);
+  for (int64_t j = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) tq_body_adam(a, j);
+}
+
+// single-GPU step: finish of the cross-unit sums + all global sites + total ELBO in ONE workgroup of 4 waves
+// (one wave per SIMD, so the fp64 site code keeps the full register file); sites are taken round-robin
+__global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
+  __shared__ double s_red[256];
+  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+  const int nq = 3 + 3 * a.C;
+  for (int j = 0; j < nq; ++j) {
+    double s = 0.0;
+    for (int64_t r = threadIdx.x; r < nblk; r += 256) s += (double)a.blk_part[r * nq + j];
+    if (j == TQ_GS_ELBO) {
+      const int nac = a.nb * a.C;
+      for (int r = threadIdx.x; r < nac; r += 256) s += (double)a.aoi_part[2 * B + r];
+    }
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.gsum[j] = s_red[0];
+    __syncthreads();
+  }
+  __threadfence_block();
+  const int ns = TQ_NGSITES(a.C);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int s = wave; s < ns; s += 4) s_e[s] = tq_body_globals_grad(a, s);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double eg = 0.0;
+    for (int j = 0; j < ns; ++j) eg += s_e[j];
+    a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -177,7 +212,7 @@ extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
   return check_launch("tq_sample_locals_kernel");
 }
 
-extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) {
+static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_sums) {
   if (int rc = check_args(a, "elbo_grads")) return rc;
   if (!a->images || !a->xy || !a->is_ontarget || !a->offset_samples || !a->offset_logits || !a->grad || !a->lat ||
       !a->site || !a->pix || !a->aoi_part || !a->blk_part || !a->gsum) {
@@ -230,9 +265,12 @@ extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) {
   hipLaunchKernelGGL(tq_aoi_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, st, *a, B);
   if (int rc = check_launch("tq_aoi_kernel")) return rc;
   // 4. cross-unit sums
+  if (!finish_sums) return TQ_OK;
   hipLaunchKernelGGL(tq_reduce_kernel, dim3(1), dim3(256), 0, st, *a, nblk, B);
   return check_launch("tq_reduce_kernel");
 }
+
+extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) { return elbo_grads_impl(a, stream, true); }
 
 extern "C" int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "globals_grad")) return rc;
@@ -256,16 +294,60 @@ extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {
     return TQ_ERR_ARG;
   }
   const int64_t total = tq_cosmos_param_count(a->Nt, a->F, a->C, a->K);
-  int64_t nblk = (total + 255) / 256;
+  // with fuse_adam the local block was already updated by the per-unit kernel
+  const int64_t first = a->fuse_adam ? tq_aoi_base(*a) : 0;
+  int64_t nblk = (total - first + 255) / 256;
   if (nblk > 256 * 16) nblk = 256 * 16;  // grid-stride: 16 workgroups per CU
-  hipLaunchKernelGGL(tq_adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, *a, total);
+  hipLaunchKernelGGL(tq_adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, *a, first, total);
   return check_launch("tq_adam_kernel");
 }
 
 extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {
   if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
   if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
-  if (int rc = tq_cosmos_elbo_grads(a, stream)) return rc;
-  if (int rc = tq_cosmos_globals_grad(a, stream)) return rc;
+  if (int rc = elbo_grads_impl(a, stream, false)) return rc;
+  if (!a->grad || !a->gsum || !a->elbo_out) {
+    tq_set_error("tq_cosmos_step: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  // no all-reduce on this path: sums, global sites and the total ELBO finish in one launch
+  const int64_t B = tq_batch_units(*a);
+  hipLaunchKernelGGL(tq_reduce_globals_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, tq_cosmos_nblk(B), B);
+  if (int rc = check_launch("tq_reduce_globals_kernel")) return rc;
   return tq_cosmos_adam(a, stream);
+}
+
+// ---- posterior read-out (cosmos.compute_probs) -------------------------------------------------------------
+__global__ __launch_bounds__(64) void tq_probs_globals_kernel(const tq_probs_args a) {
+  if (threadIdx.x == 0) tq_body_probs_globals(a, blockIdx.x, blockIdx.y);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void tq_probs_kernel(const tq_probs_args a, const int64_t U) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u < U) tq_body_probs_unit<K>(a, u);
+}
+
+extern "C" int tq_cosmos_probs(const tq_probs_args* a, void* stream) {
+  if (!a || !a->params || !a->is_ontarget || !a->globals_p || !a->gbase_p || !a->z_probs || !a->theta_probs ||
+      (!a->draw && !a->xy_given)) {
+    tq_set_error("tq_cosmos_probs: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  if (a->K < 1 || a->K > TQ_MAX_K || a->C < 1 || a->C > TQ_MAXQ || a->particles < 1 || a->particles > 65535) {
+    tq_set_error("tq_cosmos_probs: unsupported K/C/particles");
+    return TQ_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tq_probs_globals_kernel, dim3(TQ_NGSITES(a->C), a->particles), dim3(64), 0, st, *a);
+  if (int rc = check_launch("tq_probs_globals_kernel")) return rc;
+  const int64_t U = (int64_t)a->Nt * a->F * a->C;
+  const dim3 grid((unsigned)((U + 255) / 256)), block(256);
+  switch (a->K) {
+    case 1: hipLaunchKernelGGL((tq_probs_kernel<1>), grid, block, 0, st, *a, U); break;
+    case 2: hipLaunchKernelGGL((tq_probs_kernel<2>), grid, block, 0, st, *a, U); break;
+    case 3: hipLaunchKernelGGL((tq_probs_kernel<3>), grid, block, 0, st, *a, U); break;
+    default: hipLaunchKernelGGL((tq_probs_kernel<4>), grid, block, 0, st, *a, U); break;
+  }
+  return check_launch("tq_probs_kernel");
 }

@@ -45,6 +45,57 @@
 #define TQ_FRCP(x) (1.0f / (x))
 #endif
 
+
+// ------------------------------------------------------------------------------------------
+// fp64 reciprocal / square root / logarithm from fp32 hardware seeds + Newton steps (relative error
+// < 1e-13, arguments well inside the float range).  The library versions cost 25-100 instructions
+// each and dominated the implicit-gradient code, whose results are rounded to float anyway.
+// ------------------------------------------------------------------------------------------
+TQ_HD double tq_drcp(double b) {
+  double y = (double)TQ_FRCP((float)b);
+  double e = fma(-b, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-b, y, 1.0);
+  return fma(y, e, y);
+}
+TQ_HD double tq_dsqrt(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = (double)__builtin_amdgcn_rsqf((float)a);
+#else
+  const double r = (double)(1.0f / sqrtf((float)a));
+#endif
+  double g = a * r, h = 0.5 * r;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  return fma(g, e, g);
+}
+TQ_HD double tq_dlog(double z) {
+  // z = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh((m-1)/(m+1))
+  union { double d; long long i; } u;
+  u.d = z;
+  int e = (int)((u.i >> 52) & 0x7ff) - 1023;
+  u.i = (u.i & 0x000fffffffffffffLL) | 0x3ff0000000000000LL;
+  double m = u.d;
+  if (m > 1.41421356237309504880) {
+    m *= 0.5;
+    e += 1;
+  }
+  const double s = (m - 1.0) * tq_drcp(m + 1.0);
+  const double s2 = s * s;
+  double p = 1.0 / 17.0;
+  p = fma(p, s2, 1.0 / 15.0);
+  p = fma(p, s2, 1.0 / 13.0);
+  p = fma(p, s2, 1.0 / 11.0);
+  p = fma(p, s2, 1.0 / 9.0);
+  p = fma(p, s2, 1.0 / 7.0);
+  p = fma(p, s2, 1.0 / 5.0);
+  p = fma(p, s2, 1.0 / 3.0);
+  p = fma(p, s2, 1.0);
+  return fma((double)e, 0.69314718055994530942, 2.0 * s * p);
+}
+
 #define TQ_LN_SQRT_2PI 0.91893853320467274178f
 #define TQ_LN2 0.69314718055994530942f
 #define TQ_PI 3.14159265358979323846f
@@ -108,41 +159,56 @@ TQ_HD float tq_uniform(TqPhilox* s) {
   return (float)(tq_philox_next(s) >> 8) * 5.9604644775390625e-08f + 2.98023223876953125e-08f;
 }
 
-TQ_HD float tq_normal(TqPhilox* s) {  // Box-Muller, one value per call (the sine branch is dropped)
-  const float u1 = tq_uniform(s);
-  const float u2 = tq_uniform(s);
+// Box-Muller: both normals of one (u1, u2) pair
+TQ_HD void tq_normal_pair(float u1, float u2, float* x1, float* x2) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  // v_cos_f32 takes its argument in revolutions: cos(2 pi u2) is one instruction
-  return __builtin_amdgcn_sqrtf(-2.0f * TQ_FLOG(u1)) * __builtin_amdgcn_cosf(u2);
+  // v_cos_f32 / v_sin_f32 take their argument in revolutions
+  const float r = __builtin_amdgcn_sqrtf(-2.0f * TQ_FLOG(u1));
+  *x1 = r * __builtin_amdgcn_cosf(u2);
+  *x2 = r * __builtin_amdgcn_sinf(u2);
 #else
-  return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * TQ_PI * u2);
+  const float r = sqrtf(-2.0f * logf(u1));
+  *x1 = r * cosf(2.0f * TQ_PI * u2);
+  *x2 = r * sinf(2.0f * TQ_PI * u2);
 #endif
 }
 
-// Standard Gamma(alpha, 1) draw; Marsaglia & Tsang (2000) with the alpha < 1 boost.
+// Standard Gamma(alpha, 1) draw; Marsaglia & Tsang (2000) with the alpha < 1 boost (the algorithm of
+// torch's sample_gamma).  One Philox block (4 words) feeds TWO independent candidates -- the two
+// Box-Muller normals and two uniforms -- evaluated in straight-line code; the first accepted one is
+// returned.  A lane needs a second block with probability ~1e-3, so a wave64 almost never loops.
 TQ_HD float tq_sample_std_gamma(TqPhilox* s, float alpha) {
   float scale = 1.0f;
   if (alpha < 1.0f) {
     if (alpha == 0.0f) return 0.0f;
     scale = powf(1.0f - tq_uniform(s), 1.0f / alpha);
     alpha += 1.0f;
+    s->have = 0;  // the candidates below start on a fresh block
   }
   const float d = alpha - 1.0f / 3.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float c = __builtin_amdgcn_rsqf(9.0f * d);
+#else
   const float c = 1.0f / sqrtf(9.0f * d);
-  for (int it = 0; it < 64; ++it) {  // acceptance > 95 %; the bound only guards against a stuck wave
-    float x, y;
-    int guard = 0;
-    do {
-      x = tq_normal(s);
-      y = 1.0f + c * x;
-    } while (y <= 0.0f && ++guard < 64);
-    const float v = y * y * y;
-    const float u = 1.0f - tq_uniform(s);
-    const float xx = x * x;
-    if (u < 1.0f - 0.0331f * xx * xx) return scale * d * v;
-    if (logf(u) < 0.5f * xx + d * (1.0f - v + logf(v))) return scale * d * v;
+#endif
+  for (int it = 0; it < 32; ++it) {  // the bound only guards against a stuck wave
+    const float ua = tq_uniform(s), ub = tq_uniform(s);
+    const float u[2] = {1.0f - tq_uniform(s), 1.0f - tq_uniform(s)};
+    float x[2];
+    tq_normal_pair(ua, ub, &x[0], &x[1]);
+    float out = -1.0f;
+#pragma unroll
+    for (int j = 1; j >= 0; --j) {  // candidate 0 has priority: evaluated last so that it overwrites
+      const float y = 1.0f + c * x[j];
+      const float v = y * y * y;
+      const float xx = x[j] * x[j];
+      const bool ok = (y > 0.0f) && ((u[j] < 1.0f - 0.0331f * xx * xx) ||
+                                     (TQ_FLOG(u[j]) < 0.5f * xx + d * (1.0f - v + TQ_FLOG(fmaxf(v, 1e-37f)))));
+      if (ok) out = d * v;
+    }
+    if (out >= 0.0f) return scale * out;
   }
-  return scale * d;  // practically unreachable (p < 1e-80)
+  return scale * d;  // practically unreachable
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,7 +273,7 @@ TQ_HD float tq_digamma(float a) {
 }
 
 TQ_HD void tq_lgamma_digamma(float a, float* lg, float* dg) {
-  const float lna = logf(a), ra = 1.0f / a;
+  const float lna = TQ_FLOG(a), ra = TQ_FRCP(a);
   float S, dS;
   tq_binet(a, lna, ra, &S, &dS);
   *lg = (a - 0.5f) * lna - a + TQ_LN_SQRT_2PI + S;
@@ -232,13 +298,13 @@ TQ_HD_NOINLINE void tq_lgamma_digamma_d(double a, double* lg, double* dg) {
 // ------------------------------------------------------------------------------------------
 // numerically safe logistic helpers (unconstrained -> constrained transforms)
 // ------------------------------------------------------------------------------------------
-TQ_HD float tq_softplus(float u) {  // ln(1 + e^u)
-  return u > 0.0f ? u + log1pf(expf(-u)) : log1pf(expf(u));
+TQ_HD float tq_softplus(float u) {  // ln(1 + e^u) = max(u, 0) + ln(1 + e^-|u|)
+  return fmaxf(u, 0.0f) + log1pf(TQ_FEXP(-fabsf(u)));
 }
-TQ_HD float tq_sigmoid(float u) {
-  if (u >= 0.0f) return 1.0f / (1.0f + expf(-u));
-  const float e = expf(u);
-  return e / (1.0f + e);
+TQ_HD float tq_sigmoid(float u) {  // branch-free: e = e^-|u| in (0, 1]
+  const float e = TQ_FEXP(-fabsf(u));
+  const float r = TQ_FRCP(1.0f + e);
+  return u >= 0.0f ? r : e * r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,24 +336,27 @@ TQ_HD_NOINLINE float tq_std_gamma_grad(float alpha_, float x_) {
   if (alpha > 8.0) {  // Rice saddle-point expansion
     if (0.9 * alpha <= x && x <= 1.1 * alpha) {
       const double numer_1 = 1.0 + 24.0 * alpha * (1.0 + 12.0 * alpha);
-      const double numer_2 = 1440.0 * (alpha * alpha) + 6.0 * x * (53.0 - 120.0 * x) - 65.0 * x * x / alpha +
+      const double numer_2 = 1440.0 * (alpha * alpha) + 6.0 * x * (53.0 - 120.0 * x) - 65.0 * x * x * tq_drcp(alpha) +
                              alpha * (107.0 + 3600.0 * x);
       const double denom = 1244160.0 * (alpha * alpha) * (alpha * alpha);
-      return (float)(numer_1 * numer_2 / denom);
+      return (float)(numer_1 * numer_2 * tq_drcp(denom));
     }
-    const double denom = sqrt(8.0 * alpha);
-    const double term2 = denom / (alpha - x);
-    const double t3b = x - alpha - alpha * log(x / alpha);
-    const double term3 = 1.0 / (t3b * sqrt(t3b));  // t3b^(-3/2)
+    const double ra = tq_drcp(alpha);
+    const double denom = tq_dsqrt(8.0 * alpha);
+    const double rax = tq_drcp(alpha - x);
+    const double term2 = denom * rax;
+    const double lxa = tq_dlog(x * ra);
+    const double t3b = x - alpha - alpha * lxa;
+    const double term3 = tq_drcp(t3b * tq_dsqrt(t3b));  // t3b^(-3/2)
     const double term23 = (x < alpha) ? term2 - term3 : term2 + term3;
-    const double term1 = log(x / alpha) * term23 - sqrt(2.0 / alpha) * (alpha + x) / ((alpha - x) * (alpha - x));
-    const double stirling = 1.0 + 1.0 / (12.0 * alpha) * (1.0 + 1.0 / (24.0 * alpha));
+    const double term1 = lxa * term23 - tq_dsqrt(2.0 * ra) * (alpha + x) * rax * rax;
+    const double stirling = 1.0 + ra * (1.0 / 12.0) * (1.0 + ra * (1.0 / 24.0));
     const double numer = x * term1;
-    return (float)(-stirling * numer / denom);
+    return (float)(-stirling * numer * tq_drcp(denom));
   }
   // bivariate rational approximation in (ln(x/alpha), ln alpha); coefficients: PyTorch (BSD-3)
-  const double u = log(x / alpha);
-  const double v = log(alpha);
+  const double v = tq_dlog(alpha);
+  const double u = tq_dlog(x) - v;
   const double coef_uv[3][8] = {
       {0.16009398, -0.094634809, 0.025146376, -0.0030648343, 1, 0.32668115, 0.10406089, 0.0014179084},
       {0.53487893, 0.1298071, 0.065735949, -0.0015649758, 0.16639465, 0.020070113, -0.0035938915, -0.00058392623},
@@ -298,7 +367,7 @@ TQ_HD_NOINLINE float tq_std_gamma_grad(float alpha_, float x_) {
   for (int i = 0; i < 8; ++i) coef_v[i] = coef_uv[0][i] + u * (coef_uv[1][i] + u * coef_uv[2][i]);
   const double p = coef_v[0] + v * (coef_v[1] + v * (coef_v[2] + v * coef_v[3]));
   const double q = coef_v[4] + v * (coef_v[5] + v * (coef_v[6] + v * coef_v[7]));
-  return (float)exp(p / q);
+  return expf((float)(p * tq_drcp(q)));  // the result is a float: exp of a float-rounded argument is accurate to 1e-7
 }
 
 // ------------------------------------------------------------------------------------------
@@ -350,9 +419,9 @@ TQ_HD double tq_beta_grad_window(double x, double alpha, double beta) {
                alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2 +
                         alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta +
                                  alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
-  const double prefactor_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
-  const double prefactor_den = 12960.0 * alpha * alpha * alpha * b2 * (1.0 + 12.0 * total);
-  return prefactor_num / (1.0 - x) * poly / prefactor_den;
+  const double prefactor_num = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta);
+  const double prefactor_den = 12960.0 * alpha * alpha * alpha * b2 * (1.0 + 12.0 * total) * (total * total) * (1.0 - x);
+  return prefactor_num * poly * tq_drcp(prefactor_den);
 }
 
 TQ_HD double tq_beta_grad_alpha_mid(double x, double alpha, double beta) {
@@ -388,42 +457,46 @@ TQ_HD bool tq_beta_grad_pair_mid(double x, double alpha, double beta, double* ga
   const double total = alpha + beta;
   const double boundary = total * x * (1.0 - x);
   if (!(boundary >= 2.5 && alpha > 6.0 && beta > 6.0)) return false;
-  const double mean = alpha / total;
-  const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+  const double rt = tq_drcp(total);
+  const double mean = alpha * rt;
   const double y = 1.0 - x;
-  if (fabs(x - mean) <= 0.1 * sd) {
+  // |x - mean| <= 0.1 sd, sd^2 = alpha beta / ((total+1) total^2), without the square root
+  const double dev = x - mean;
+  if (dev * dev * (total + 1.0) * total * total <= 0.01 * alpha * beta) {
     // removable singularity at x = mean: both directions use the local polynomial (8 % of draws;
     // handled here so that a wave never has to run the generic piecewise code for them)
     *ga = tq_beta_grad_window(x, alpha, beta);
     *gb = tq_beta_grad_window(y, beta, alpha);
     return true;
   }
-  const double rt = 1.0 / total;
-  const double la = log(alpha * rt / x);  // ln(alpha / (total x))
-  const double lb = log(beta * rt / y);   // ln(beta / (total (1-x)))
+  const double la = tq_dlog(alpha * rt * tq_drcp(x));  // ln(alpha / (total x))
+  const double lb = tq_dlog(beta * rt * tq_drcp(y));   // ln(beta / (total (1-x)))
   const double base = beta * lb + alpha * la;            // total * KL(mean || x) > 0
-  const double term4 = 1.0 / (base * sqrt(base));        // base^(-3/2)
-  const double s2 = sqrt(2.0 * alpha * beta * rt);       // sqrt(2 alpha beta / total)
-  const float fa = 1.0f / (12.0f * (float)alpha), fb = 1.0f / (12.0f * (float)beta), ft = 1.0f / (12.0f * (float)total);
-  const double stirling = (double)((1.0f + fa + 0.5f * fa * fa) * (1.0f + fb + 0.5f * fb * fb) / (1.0f + ft + 0.5f * ft * ft));
+  const double sb = tq_dsqrt(base);
+  const double term4 = tq_drcp(base * sb);               // base^(-3/2)
+  const double s2 = tq_dsqrt(2.0 * alpha * beta * rt);   // sqrt(2 alpha beta / total)
+  const double rs2 = tq_drcp(s2);
+  const float fa = TQ_FRCP(12.0f * (float)alpha), fb = TQ_FRCP(12.0f * (float)beta), ft = TQ_FRCP(12.0f * (float)total);
+  const double stirling =
+      (double)((1.0f + fa + 0.5f * fa * fa) * (1.0f + fb + 0.5f * fb * fb) * TQ_FRCP(1.0f + ft + 0.5f * ft * ft));
   const double axbx = beta * x - alpha * y;              // alpha (x-1) + beta x = total (x - mean)
-  const double r_ax = 1.0 / axbx;
-  const double t15 = total * sqrt(total);
-  const double sab = sqrt(alpha / beta);                 // sqrt(2 alpha / beta) = sqrt(2) sab
-  const double r_den = r_ax * r_ax / (1.41421356237309504880 * t15);
+  const double r_ax = tq_drcp(axbx);
+  const double st = tq_dsqrt(total);
+  const double sab = tq_dsqrt(alpha * tq_drcp(beta));    // sqrt(alpha / beta); sqrt(2 alpha / beta) = sqrt(2) sab
+  const double r_den = r_ax * r_ax * tq_drcp(1.41421356237309504880 * total * st);
   const double term3 = 2.0 * s2 * r_ax;                  // sqrt(8 alpha beta / total) / axbx
   const double sgn4 = (x < mean) ? term4 : -term4;
   // direction alpha
   {
     const double num = -(2.0 * alpha * alpha + alpha * beta) * y - x * beta * beta;
-    const double term1 = num * r_den / sab;
-    *ga = stirling * (-x / s2) * (term1 + 0.5 * la * (term3 + sgn4));
+    const double term1 = num * r_den * tq_drcp(sab);
+    *ga = stirling * (-x * rs2) * (term1 + 0.5 * la * (term3 + sgn4));
   }
   // direction beta: x -> 1-x, alpha <-> beta, axbx -> -axbx, mean -> 1-mean
   {
     const double num = -(2.0 * beta * beta + alpha * beta) * x - y * alpha * alpha;
     const double term1 = num * r_den * sab;
-    *gb = stirling * (-y / s2) * (term1 + 0.5 * lb * (-term3 - sgn4));
+    *gb = stirling * (-y * rs2) * (term1 + 0.5 * lb * (-term3 - sgn4));
   }
   return true;
 }

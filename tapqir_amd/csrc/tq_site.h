@@ -62,26 +62,27 @@ struct TqSiteConsts {
 //   = -ln v + alpha phi(v/loc) + (1/2) ln alpha - ln sqrt(2pi) - S(alpha)
 TQ_HD void tq_gamma_logpdf(float v, float loc, float beta, float* lp, float* d_v, float* d_alpha, float* d_beta) {
   const float alpha = loc * beta;
-  const float rho = v / loc;
-  const float lrho = log1pf((v - loc) / loc);
-  const float lna = logf(alpha), ra = 1.0f / alpha;
+  const float rloc = TQ_FRCP(loc);
+  const float rho = v * rloc;
+  const float lrho = log1pf((v - loc) * rloc);
+  const float lna = TQ_FLOG(alpha), ra = TQ_FRCP(alpha);
   float S, dS;
   tq_binet(alpha, lna, ra, &S, &dS);
-  *lp = -logf(v) + alpha * (lrho + 1.0f - rho) + 0.5f * lna - TQ_LN_SQRT_2PI - S;
-  *d_v = (alpha - 1.0f) / v - beta;
+  *lp = -TQ_FLOG(v) + alpha * (lrho + 1.0f - rho) + 0.5f * lna - TQ_LN_SQRT_2PI - S;
+  *d_v = (alpha - 1.0f) * TQ_FRCP(v) - beta;
   *d_alpha = lrho + 0.5f * ra - dS;  // = ln beta + ln v - digamma(alpha)
   *d_beta = loc - v;                 // = alpha / beta - v
 }
 
 // Beta(t; c1, c0)
 TQ_HD void tq_beta_logpdf(float t, float c1, float c0, float* lp, float* d_t, float* d_c1, float* d_c0) {
-  const float lt = logf(t), l1t = log1pf(-t);
+  const float lt = TQ_FLOG(t), l1t = TQ_FLOG(1.0f - t);
   float lg1, dg1, lg0, dg0, lgt, dgt;
   tq_lgamma_digamma(c1, &lg1, &dg1);
   tq_lgamma_digamma(c0, &lg0, &dg0);
   tq_lgamma_digamma(c1 + c0, &lgt, &dgt);
   *lp = (c1 - 1.0f) * lt + (c0 - 1.0f) * l1t + lgt - lg1 - lg0;
-  *d_t = (c1 - 1.0f) / t - (c0 - 1.0f) / (1.0f - t);
+  *d_t = (c1 - 1.0f) * TQ_FRCP(t) - (c0 - 1.0f) * TQ_FRCP(1.0f - t);
   *d_c1 = lt - dg1 + dgt;
   *d_c0 = l1t - dg0 + dgt;
 }
@@ -102,19 +103,20 @@ TQ_HD void tq_gamma_site_terms(float v, float loc, float beta, float* s) {
   s[1] = d_v;
   s[2] = d_alpha;
   s[3] = d_beta;
-  s[4] = tq_std_gamma_grad(loc * beta, v * beta) / beta;
+  s[4] = tq_std_gamma_grad(loc * beta, v * beta) * TQ_FRCP(beta);
   s[5] = 0.0f;
 }
 
 TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low, float high, float eps, float* s) {
   const float sc = high - low;
-  const float t = (y - low) / sc;
-  const float c1 = size * (mean - low) / sc;
-  const float c0 = size * (high - mean) / sc;
+  const float rsc = TQ_FRCP(sc);
+  const float t = (y - low) * rsc;
+  const float c1 = size * (mean - low) * rsc;
+  const float c0 = size * (high - mean) * rsc;
   float lq, d_t, d_c1, d_c0;
   tq_beta_logpdf(t, c1, c0, &lq, &d_t, &d_c1, &d_c0);
-  s[0] = lq - logf(sc);
-  s[1] = d_t / sc;
+  s[0] = lq - TQ_FLOG(sc);
+  s[1] = d_t * rsc;
   s[2] = d_c1;
   s[3] = d_c0;
   // pathwise: y = low + sc * t unless clamped by rsample
@@ -141,7 +143,7 @@ TQ_HD void tq_gamma_site_chain(const float* s, float v, float loc, float beta, f
   const float alpha = loc * beta;
   const float ev_tot = e_v - wq * s[1];
   const float g_alpha = ev_tot * s[4] - wq * s[2];
-  const float g_beta_direct = ev_tot * (-v / beta) - wq * s[3];
+  const float g_beta_direct = ev_tot * (-v * TQ_FRCP(beta)) - wq * s[3];
   *d_loc_u = g_alpha * alpha;                          // alpha = loc*beta; loc = exp(u_loc)
   *d_beta_u = g_alpha * alpha + g_beta_direct * beta;  // beta = exp(u_beta)
 }
@@ -149,12 +151,12 @@ TQ_HD void tq_gamma_site_chain(const float* s, float v, float loc, float beta, f
 // chain rule of one AffineBeta site -> d objective / d mean, d size (constrained parameters)
 TQ_HD void tq_affine_beta_site_chain(const float* s, float mean, float size, float low, float high, float e_y,
                                      float wq, float* d_mean, float* d_size) {
-  const float sc = high - low;
+  const float rsc = TQ_FRCP(high - low);
   const float ey_tot = e_y - wq * s[1];
   const float g_c1 = ey_tot * s[4] - wq * s[2];
   const float g_c0 = ey_tot * s[5] - wq * s[3];
-  *d_mean = (g_c1 - g_c0) * size / sc;
-  *d_size = g_c1 * (mean - low) / sc + g_c0 * (high - mean) / sc;
+  *d_mean = (g_c1 - g_c0) * size * rsc;
+  *d_size = (g_c1 * (mean - low) + g_c0 * (high - mean)) * rsc;
 }
 
 // ---- inputs / outputs of the per-unit routine ---------------------------------------------------
@@ -201,21 +203,25 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
   // ---- z / theta marginal L(m) and its derivatives -----------------------------------------------
   const float rho = in.on ? G.rho[q] : 0.0f;
   const float a = G.a[q], c = G.c[q];
-  const float ln_a = logf(a), ln_1ma = log1pf(-a);
-  const float ln_c = (K > 1) ? logf(c) : 0.0f, ln_1mc = (K > 1) ? log1pf(-c) : 0.0f;
-  const float ln_1mrho = log1pf(-rho);
-  const float ln_rhoK = in.on ? logf(rho / (float)K) : -INFINITY;
-  const float lu = -2.0f * logf(2.0f * H);  // log uniform density of (x, y) on (-H, H)^2
+  const float ln_a = TQ_FLOG(a), ln_1ma = TQ_FLOG(1.0f - a);
+  const float ln_c = (K > 1) ? TQ_FLOG(c) : 0.0f, ln_1mc = (K > 1) ? TQ_FLOG(1.0f - c) : 0.0f;
+  const float ln_1mrho = TQ_FLOG(1.0f - rho);
+  const float ln_rhoK = in.on ? TQ_FLOG(rho * (1.0f / (float)K)) : -INFINITY;
+  const float r2H = TQ_FRCP(2.0f * H);
+  const float lu = 2.0f * TQ_FLOG(r2H);  // log uniform density of (x, y) on (-H, H)^2
+  const float ra_ = TQ_FRCP(a), r1a_ = TQ_FRCP(1.0f - a);
+  const float rc_ = (K > 1) ? TQ_FRCP(c) : 0.0f, r1c_ = (K > 1) ? TQ_FRCP(1.0f - c) : 0.0f;
+  const float rrho_ = in.on ? TQ_FRCP(rho) : 0.0f, r1rho_ = TQ_FRCP(1.0f - rho);
   const float cs = G.cs;
   float tsum[K], sxy[K], dsx[K], dsy[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const float tx = (in.x[k] + H) / (2.0f * H), ty = (in.y[k] + H) / (2.0f * H);
+    const float tx = (in.x[k] + H) * r2H, ty = (in.y[k] + H) * r2H;
     const float ex = 2.0f * tx - 1.0f, ey = 2.0f * ty - 1.0f;
     tsum[k] = log1pf(-ex * ex) + log1pf(-ey * ey);  // ln[4 tx (1-tx)] + ln[4 ty (1-ty)]
     sxy[k] = (cs - 1.0f) * tsum[k] - 2.0f * G.lnB_s + lu;
-    dsx[k] = (cs - 1.0f) * (1.0f / tx - 1.0f / (1.0f - tx)) / (2.0f * H);
-    dsy[k] = (cs - 1.0f) * (1.0f / ty - 1.0f / (1.0f - ty)) / (2.0f * H);
+    dsx[k] = (cs - 1.0f) * (TQ_FRCP(tx) - TQ_FRCP(1.0f - tx)) * r2H;
+    dsy[k] = (cs - 1.0f) * (TQ_FRCP(ty) - TQ_FRCP(1.0f - ty)) * r2H;
   }
 
   float Lm[M], Wm[M];
@@ -249,23 +255,23 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
     float se = 0.0f, r[K + 1];
 #pragma unroll
     for (int th = 0; th <= K; ++th) {
-      r[th] = expf(T[th] - mx);
+      r[th] = TQ_FEXP(T[th] - mx);
       se += r[th];
     }
-    Lm[mi] = mx + logf(se);
-    const float rse = 1.0f / se;
+    Lm[mi] = mx + TQ_FLOG(se);
+    const float rse = TQ_FRCP(se);
 #pragma unroll
     for (int th = 0; th <= K; ++th) r[th] *= rse;
     // derivatives of L(m), weighted by the Dice weight
-    d_a += w * r[0] * (fn1 / a - fn0 / (1.0f - a));
+    d_a += w * r[0] * (fn1 * ra_ - fn0 * r1a_);
     float rsum = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       rsum += r[k + 1];
       dS[k] += w * r[k + 1];
     }
-    if (K > 1) d_c += w * rsum * ((fn1 - 1.0f) / c - fn0 / (1.0f - c));
-    if (in.on) d_rho += w * (-r[0] / (1.0f - rho) + rsum / rho);
+    if (K > 1) d_c += w * rsum * ((fn1 - 1.0f) * rc_ - fn0 * r1c_);
+    if (in.on) d_rho += w * (-r[0] * r1rho_ + rsum * rrho_);
   }
 
   // ---- per-spot continuous sites (densities / implicit gradients precomputed per site) -------------
@@ -275,10 +281,10 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
   for (int k = 0; k < K; ++k) {
     const float wq = wu * p1[k];
     // height: prior HalfNormal(height_std), guide Gamma(h_loc*h_beta, h_beta)
-    const float hl = expf(in.u[TQ_ROW(TQ_P_HLOC, k, K)]), hb = expf(in.u[TQ_ROW(TQ_P_HBETA, k, K)]);
-    const float hs = C.height_std;
-    const float lp_h = TQ_LN2 - logf(hs) - TQ_LN_SQRT_2PI - in.h[k] * in.h[k] / (2.0f * hs * hs);
-    const float e_h = in.gh[k] + wq * (-in.h[k] / (hs * hs));
+    const float hl = TQ_FEXP(in.u[TQ_ROW(TQ_P_HLOC, k, K)]), hb = TQ_FEXP(in.u[TQ_ROW(TQ_P_HBETA, k, K)]);
+    const float hs = C.height_std, rhs2 = TQ_FRCP(hs * hs);
+    const float lp_h = TQ_LN2 - TQ_FLOG(hs) - TQ_LN_SQRT_2PI - 0.5f * in.h[k] * in.h[k] * rhs2;
+    const float e_h = in.gh[k] + wq * (-in.h[k] * rhs2);
     tq_gamma_site_chain(in.sh[k], in.h[k], hl, hb, e_h, wq, &out->g[TQ_ROW(TQ_P_HLOC, k, K)],
                         &out->g[TQ_ROW(TQ_P_HBETA, k, K)]);
     float t_k = lp_h - in.sh[k][0];
@@ -287,16 +293,16 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
       const float sg = tq_sigmoid(in.u[TQ_ROW(TQ_P_WMEAN, k, K)]);
       const float lo = C.w_lo + eps, hi = C.w_hi - eps;
       const float mean = lo + (hi - lo) * sg;
-      const float ex = expf(in.u[TQ_ROW(TQ_P_WSIZE, k, K)]);
+      const float ex = TQ_FEXP(in.u[TQ_ROW(TQ_P_WSIZE, k, K)]);
       float d_mean, d_size;
       tq_affine_beta_site_chain(in.sw[k], mean, 2.0f + ex, C.w_lo, C.w_hi, in.gw[k], wq, &d_mean, &d_size);
       out->g[TQ_ROW(TQ_P_WMEAN, k, K)] = d_mean * (hi - lo) * sg * (1.0f - sg);
       out->g[TQ_ROW(TQ_P_WSIZE, k, K)] = d_size * ex;
-      t_k += -logf(w_sc) - in.sw[k][0];
+      t_k += -TQ_FLOG(w_sc) - in.sw[k][0];
     }
     // x, y: guide AffineBeta(mean, size, -H, H); model-side dependence through L(m)
     {
-      const float ex = expf(in.u[TQ_ROW(TQ_P_SIZE, k, K)]);
+      const float ex = TQ_FEXP(in.u[TQ_ROW(TQ_P_SIZE, k, K)]);
       const float size = 2.0f + ex;
       const float lo = -H + eps, hi = H - eps;
       const float sgx = tq_sigmoid(in.u[TQ_ROW(TQ_P_XMEAN, k, K)]);
@@ -338,15 +344,15 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
 
   // ---- background: prior Gamma((mu_b/sigma_b)^2, mu_b/sigma_b^2), guide Gamma(b_loc*b_beta, b_beta) ---
   {
-    const float mub = expf(in.u_bml), sgb = expf(in.u_bsl);
-    const float r0 = mub / (sgb * sgb);
+    const float mub = TQ_FEXP(in.u_bml), sgb = TQ_FEXP(in.u_bsl);
+    const float r0 = mub * TQ_FRCP(sgb * sgb);
     float lp_b, d_v, d_alpha, d_beta;
     tq_gamma_logpdf(in.b, mub, r0, &lp_b, &d_v, &d_alpha, &d_beta);  // loc = a0/r0 = mu_b
     const float a0 = mub * r0;
     // a0 = mu^2/sigma^2, r0 = mu/sigma^2 ; d/d ln mu and d/d ln sigma
     out->g_bml = wu * (d_alpha * 2.0f * a0 + d_beta * r0);
     out->g_bsl = wu * (d_alpha * -2.0f * a0 + d_beta * -2.0f * r0);
-    const float bl = expf(in.u[TQ_ROW_BLOC(K)]), bb = expf(in.u[TQ_ROW_BBETA(K)]);
+    const float bl = TQ_FEXP(in.u[TQ_ROW_BLOC(K)]), bb = TQ_FEXP(in.u[TQ_ROW_BBETA(K)]);
     const float e_b = in.gb + wu * d_v;
     tq_gamma_site_chain(in.sb, in.b, bl, bb, e_b, wu, &out->g[TQ_ROW_BLOC(K)], &out->g[TQ_ROW_BBETA(K)]);
     Esum += lp_b - in.sb[0];
@@ -361,6 +367,61 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
   out->d_c = wu * d_c;
   out->d_cs = wu * d_cs;
   out->elbo = wu * Esum;
+}
+
+// ---- posterior responsibilities (cosmos.compute_probs, cosmos.py:609-672) ---------------------------
+// R[k] = sum_m prod_k q(m_k) * r(z = 1, theta = k+1 | m) for one unit and one joint draw of (pi, lamda,
+// proximity, x, y).  Same marginal as L(m) above.
+template <int K>
+TQ_HD void tq_zt_responsibilities(const float* x, const float* y, const float* u_mprobs, const TqGlobals& G, int q,
+                                  float H, float* R) {
+  constexpr int M = 1 << K;
+  const float rho = G.rho[q], a = G.a[q], c = G.c[q];
+  const float ln_a = logf(a), ln_1ma = log1pf(-a);
+  const float ln_c = (K > 1) ? logf(c) : 0.0f, ln_1mc = (K > 1) ? log1pf(-c) : 0.0f;
+  const float ln_1mrho = log1pf(-rho), ln_rhoK = logf(rho / (float)K);
+  const float lu = -2.0f * logf(2.0f * H);
+  float sxy[K], p1[K], p0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float ex = x[k] / H, ey = y[k] / H;  // 2t - 1
+    sxy[k] = (G.cs - 1.0f) * (log1pf(-ex * ex) + log1pf(-ey * ey)) - 2.0f * G.lnB_s + lu;
+    p1[k] = tq_sigmoid(u_mprobs[k]);
+    p0[k] = tq_sigmoid(-u_mprobs[k]);
+    R[k] = 0.0f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) {
+    int n1 = 0;
+    float w = 1.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      n1 += (mi >> k) & 1;
+      w *= ((mi >> k) & 1) ? p1[k] : p0[k];
+    }
+    const float fn1 = (float)n1, fn0 = (float)(K - n1);
+    float T[K + 1];
+    T[0] = ln_1mrho + fn1 * ln_a + fn0 * ln_1ma + fn1 * lu;
+    float mx = T[0];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if ((mi >> k) & 1) {
+        T[k + 1] = ln_rhoK + sxy[k] + (fn1 - 1.0f) * lu + fn0 * ln_1mc;
+        if (K > 1 && n1 > 1) T[k + 1] += (fn1 - 1.0f) * ln_c;
+      } else {
+        T[k + 1] = -INFINITY;
+      }
+      mx = fmaxf(mx, T[k + 1]);
+    }
+    float se = 0.0f, r[K + 1];
+#pragma unroll
+    for (int th = 0; th <= K; ++th) {
+      r[th] = expf(T[th] - mx);
+      se += r[th];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) R[k] += w * r[k + 1] / se;
+  }
 }
 
 // ---- per-AOI prior terms (cosmos.py:221-227): HalfNormal(mu_b; s1) + HalfNormal(sigma_b; s2) ------

@@ -1,0 +1,136 @@
+"""
+``KSMOGN`` -- K-Spots Marginalised-Offset Gamma-Noise image distribution (drop-in for
+tapqir/distributions/ksmogn.py:21-238, cosmos branch), evaluated by the fused HIP kernel
+``tq_ksmogn_log_prob`` (include/tapqir_hip.h) instead of KeOps / dense torch.
+
+    mu[j, i] = background + sum_k m_k h_k N(i; x_k + tx, w_k) N(j; y_k + ty, w_k)
+    p(D | mu, g) = sum_o w_o Gamma(D - delta_o; mu / g, 1 / g),  D > delta_o
+
+``log_prob`` is differentiable w.r.t. height, width, x, y, background and gain (the kernel's fused
+backward).  There is no CPU path: tensors must live on the HIP device.
+"""
+
+import ctypes as C
+
+import torch
+from torch.distributions import Categorical, constraints
+from torch.distributions.distribution import Distribution
+
+from tapqir_amd import _lib
+from tapqir_amd.distributions.util import gaussian_spots
+from tapqir_amd.exceptions import HipExtensionError
+
+
+def _launch(value, h, w, x, y, xy, b, gain, offs, logits, P, K, gout=None):
+    """value (B,P,P); h,w,x,y (K,B); xy (B,2); b (B,) -> ll (2^K, B) [+ grads]."""
+    if value.device.type != "cuda":
+        raise HipExtensionError("KSMOGN.log_prob runs on the HIP device only (no CPU fallback)")
+    lib = _lib.load()
+    B, M = value.shape[0], 1 << K
+    dev, f32 = value.device, torch.float32
+    ll = torch.empty(M, B, dtype=f32, device=dev)
+    a = _lib.KsmognArgs()
+    p = _lib.ptr
+    a.images, a.images_il, a.pixstats, a.xy = p(value), None, None, p(xy)
+    a.background, a.height, a.width, a.x, a.y, a.gain = p(b), p(h), p(w), p(x), p(y), p(gain)
+    a.offset_samples, a.offset_logits = p(offs), p(logits)
+    a.ll = p(ll)
+    grads = None
+    if gout is not None:
+        grads = {n: torch.empty(K, B, dtype=f32, device=dev) for n in ("h", "w", "x", "y")}
+        grads["b"] = torch.empty(B, dtype=f32, device=dev)
+        grads["g"] = torch.empty(B, dtype=f32, device=dev)
+        a.gout = p(gout)
+        a.g_background, a.g_gain = p(grads["b"]), p(grads["g"])
+        a.g_height, a.g_width, a.g_x, a.g_y = p(grads["h"]), p(grads["w"]), p(grads["x"]), p(grads["y"])
+    a.nb, a.fb, a.C, a.F, a.P, a.K, a.O = B, 1, 1, 1, P, K, offs.numel()
+    a.nb_full, a.il_min_units, a.scale, a.m_kstride, a.stats_stride = B, 1 << 30, 1.0, B, B
+    _lib.check(lib.tq_ksmogn_log_prob(C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+               "tq_ksmogn_log_prob")
+    return ll, grads
+
+
+class _KsmognLogProb(torch.autograd.Function):
+    """The kernel evaluates every spot-presence combination of a unit; ``combo`` (B,) picks the one that the
+    caller's 0/1 presence indicators select (bit k = m_k)."""
+
+    @staticmethod
+    def forward(ctx, value, h, w, x, y, xy, b, gain, offs, logits, combo, P):
+        K = h.shape[0]
+        ll, _ = _launch(value, h, w, x, y, xy, b, gain, offs, logits, P, K)
+        ctx.save_for_backward(value, h, w, x, y, xy, b, gain, offs, logits, combo)
+        ctx.P = P
+        return ll.gather(0, combo[None])[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        value, h, w, x, y, xy, b, gain, offs, logits, combo = ctx.saved_tensors
+        K, B = h.shape
+        gout = torch.zeros(1 << K, B, dtype=torch.float32, device=value.device)
+        gout.scatter_(0, combo[None], go[None].to(torch.float32))
+        _, g = _launch(value, h, w, x, y, xy, b, gain, offs, logits, ctx.P, K, gout=gout)
+        return (None, g["h"], g["w"], g["x"], g["y"], None, g["b"], g["g"].sum().reshape(gain.shape), None, None,
+                None, None)
+
+
+class KSMOGN(Distribution):
+    r"""Same constructor as tapqir.distributions.KSMOGN (ksmogn.py:70-86); ``alpha`` (cross-talk) is not
+    supported yet and ``use_pykeops`` is accepted and ignored."""
+
+    arg_constraints = {}
+    support = constraints.positive
+
+    def __init__(self, height, width, x, y, target_locs, background, gain, offset_samples, offset_logits, P: int,
+                 m=None, alpha=None, use_pykeops: bool = True, validate_args=None):
+        if alpha is not None:
+            raise NotImplementedError("cross-talk (alpha) is not implemented in tapqir_amd yet")
+        self.height, self.width, self.x, self.y = height, width, x, y
+        self.target_locs, self.m = target_locs, m
+        self.background_ = background
+        self.gain = gain
+        self.offset_samples, self.offset_logits, self.P = offset_samples, offset_logits, P
+        batch_shape = torch.broadcast_shapes(height.shape, width.shape, x.shape, y.shape)
+        if m is not None:
+            batch_shape = torch.broadcast_shapes(batch_shape, m.shape)
+        self.K = batch_shape[-1]
+        batch_shape = torch.broadcast_shapes(batch_shape[:-1], background.shape, target_locs.shape[:-1])
+        super().__init__(batch_shape, torch.Size([P, P]), validate_args=False)
+
+    # -- dense helpers (data generation only) -----------------------------------------------------------
+    @property
+    def image(self):
+        g = gaussian_spots(self.height, self.width, self.x, self.y, self.target_locs.unsqueeze(-2), self.P, self.m)
+        return self.background_[..., None, None] + g.sum(-3)
+
+    def rsample(self, sample_shape=torch.Size()):
+        """ksmogn.py:171-185."""
+        conc = self.image / self.gain
+        shape = self._extended_shape(sample_shape)
+        odx = Categorical(logits=self.offset_logits).expand(shape).sample()
+        val = torch._standard_gamma(conc.expand(shape)) * self.gain
+        return val.clamp(min=torch.finfo(val.dtype).tiny) + self.offset_samples[odx]
+
+    sample = rsample
+
+    # -- the fused kernel ---------------------------------------------------------------------------------
+    def log_prob(self, value):
+        bs = torch.broadcast_shapes(self.batch_shape, value.shape[:-2])
+        f32 = torch.float32
+        ex = lambda t: t.to(f32).expand(bs + (self.K,)).reshape(-1, self.K).t().contiguous()
+        B = int(torch.Size(bs).numel())
+        if self.m is None:
+            combo = torch.full((B,), (1 << self.K) - 1, dtype=torch.int64, device=value.device)
+        else:  # presence indicators are 0/1 (Bernoulli draws or enumerated values, cosmos.py:262-267)
+            bits = (ex(self.m) > 0).to(torch.int64)  # (K, B)
+            combo = (bits << torch.arange(self.K, device=value.device)[:, None]).sum(0)
+        val = value.to(f32).expand(bs + (self.P, self.P)).reshape(B, self.P, self.P).contiguous()
+        xy = self.target_locs.to(f32).expand(bs + (2,)).reshape(B, 2).contiguous()
+        b = self.background_.to(f32).expand(bs).reshape(B).contiguous()
+        gain = self.gain.to(f32).reshape(-1)[:1].contiguous()
+        out = _KsmognLogProb.apply(val, ex(self.height), ex(self.width), ex(self.x), ex(self.y), xy, b, gain,
+                                   self.offset_samples.to(f32).contiguous(), self.offset_logits.to(f32).contiguous(),
+                                   combo, self.P)
+        return out.reshape(bs)
+
+
+KSpotGammaNoise = KSMOGN  # the spelling used in BASELINE.json's north_star

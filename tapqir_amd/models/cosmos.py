@@ -187,5 +187,39 @@ class cosmos(Model):
     def z_map(self) -> torch.Tensor:
         return torch.argmax(self.z_probs, dim=-1)
 
+    def z_sample(self, num_samples):
+        """cosmos.py:706-709."""
+        return torch.distributions.Categorical(self.params["z_probs"][: self.data.N]).sample((num_samples,))
+
+    @torch.no_grad()
+    def compute_params(self, CI):
+        """Credible intervals / means of the variational posteriors and the spot probabilities
+        (cosmos.py:711-784; same keys, tensors on the CPU)."""
+        from tapqir_amd.utils.stats import affine_beta_interval, dirichlet_interval, gamma_interval
+
+        cp = {n: v.detach() for n, v in self.engine.layout.constrained(self.engine.params).items()}
+        P, pr = self.data.P, self.priors
+        H = (P + 1) / 2
+        out = {}
+
+        def put(name, tup):
+            out[name] = {"LL": tup[0], "UL": tup[1], "Mean": tup[2]}
+
+        put("gain", gamma_interval(cp["gain_loc"], cp["gain_beta"], CI))
+        put("pi", dirichlet_interval(cp["pi_mean"] * cp["pi_size"], CI))
+        put("lamda", gamma_interval(cp["lamda_loc"], cp["lamda_beta"], CI))
+        put("proximity", affine_beta_interval(cp["proximity_loc"], cp["proximity_size"], 0.0, (P + 1) / math.sqrt(12), CI))
+        put("background", gamma_interval(cp["b_loc"], cp["b_beta"], CI))
+        put("height", gamma_interval(cp["h_loc"], cp["h_beta"], CI))
+        put("width", affine_beta_interval(cp["w_mean"], cp["w_size"], pr["width_min"], pr["width_max"], CI))
+        put("x", affine_beta_interval(cp["x_mean"], cp["size"], -H, H, CI))
+        put("y", affine_beta_interval(cp["y_mean"], cp["size"], -H, H, CI))
+        out["m_probs"] = self.m_probs.cpu()
+        out["z_probs"] = self.z_probs.cpu()
+        out["theta_probs"] = self.theta_probs.cpu()
+        out["z_map"] = self.z_map.cpu()
+        out["p_specific"] = out["theta_probs"].sum(0)
+        return out
+
 
 Cosmos = cosmos  # notebooks/part_iii_colab.ipynb:98 imports the capitalised spelling

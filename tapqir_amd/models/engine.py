@@ -160,6 +160,7 @@ class CosmosEngine:
         a.bias_correction1 = 1.0 - self.betas[0] ** t
         a.bias_correction2 = 1.0 - self.betas[1] ** t
         a.zero_grad = int(nb < self.Nt or fb < self.F)
+        a.fuse_adam = 0  # set by step() for full-batch steps
         a.seed = self.seed
         a.step = self.adam_step if step is None else int(step)
         return a
@@ -182,6 +183,7 @@ class CosmosEngine:
     def step(self, ndx=None, fdx=None, allreduce=None):
         """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``)."""
         a = self.make_args(ndx, fdx)
+        a.fuse_adam = int(not a.zero_grad)  # full batch: Adam on the local block is fused into the unit kernel
         if allreduce is None and not self._hostcheck:
             self.call("cosmos_step", a)
         else:

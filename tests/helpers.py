@@ -41,6 +41,8 @@ def load_hostcheck():
     lib.hc_ksmogn_log_prob.argtypes = [C.POINTER(_lib.KsmognArgs)]
     lib.hc_image_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     lib.hc_image_stats.restype = None
+    lib.hc_cosmos_probs.argtypes = [C.POINTER(_lib.ProbsArgs)]
+    lib.hc_cosmos_probs.restype = None
     for n in ("hc_cosmos_sample_globals", "hc_cosmos_sample_locals", "hc_cosmos_elbo_grads",
               "hc_cosmos_globals_grad", "hc_cosmos_adam"):
         getattr(lib, n).argtypes = [C.POINTER(_lib.CosmosArgs)]

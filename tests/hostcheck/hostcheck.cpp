@@ -318,7 +318,23 @@ void hc_cosmos_globals_grad(const tq_cosmos_args* a) {
 }
 void hc_cosmos_adam(const tq_cosmos_args* a) {
   const int64_t total = (int64_t)TQ_NLOCAL(a->K) * tq_num_units(*a) + 2 * (int64_t)a->Nt * a->C + TQ_NGLOBAL(a->C);
-  for (int64_t j = 0; j < total; ++j) tq_body_adam(*a, j);
+  for (int64_t j = a->fuse_adam ? tq_aoi_base(*a) : 0; j < total; ++j) tq_body_adam(*a, j);
 }
 
 }  // extern "C"
+
+template <int K>
+static void probs_host(const tq_probs_args& a) {
+  const int64_t U = (int64_t)a.Nt * a.F * a.C;
+  for (int64_t u = 0; u < U; ++u) tq_body_probs_unit<K>(a, u);
+}
+extern "C" void hc_cosmos_probs(const tq_probs_args* a) {
+  for (int p = 0; p < a->particles; ++p)
+    for (int s = 0; s < TQ_NGSITES(a->C); ++s) tq_body_probs_globals(*a, s, p);
+  switch (a->K) {
+    case 1: probs_host<1>(*a); break;
+    case 2: probs_host<2>(*a); break;
+    case 3: probs_host<3>(*a); break;
+    default: probs_host<4>(*a); break;
+  }
+}

@@ -1,0 +1,118 @@
+"""Drop-in surface: dataset file format, parameter layout, fit loop, checkpoints, statistics.
+On the CPU the model drives the host build of the kernels' math (injected engine, tests only); the
+gpu-marked test runs the same flow through libtapqir_hip.so."""
+
+import math
+
+import pytest
+import torch
+
+from helpers import CosmosEngine, load_hostcheck
+from tapqir_amd.exceptions import TapqirFileNotFoundError
+from tapqir_amd.models import Cosmos, Model, cosmos, models
+from tapqir_amd.models.layout import ParamLayout
+from tapqir_amd.utils.dataset import CosmosDataset, load, save
+from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+
+def test_registry_and_constructor_surface():
+    assert models["cosmos"] is cosmos and Cosmos is cosmos and issubclass(cosmos, Model)
+    m = cosmos(S=1, K=2, Q=None, device="cpu", dtype="double", use_pykeops=True)
+    assert m.name == "cosmos" and m._global_params == ["gain", "proximity", "lamda", "pi"]
+    assert m.conv_params == ["-ELBO", "proximity_loc", "gain_loc", "lamda_loc"]
+    assert m.priors["height_std"] == 10000.0 and m.priors["gain_std"] == 50.0
+    with pytest.raises(NotImplementedError):
+        cosmos(S=2)
+
+
+def test_data_tpqr_roundtrip(tmp_path):
+    d = simulate(2, 4, 5, 1, 14, 0, TEST_PARAMS)
+    save(d, tmp_path)
+    raw = torch.load(tmp_path / "data.tpqr", weights_only=False)
+    assert set(raw) == {"images", "xy", "is_ontarget", "mask", "labels", "offset_samples", "offset_weights", "name",
+                        "time1", "ttb", "channels"}  # tapqir/utils/dataset.py:195-212
+    d2 = load(tmp_path)
+    assert torch.equal(d2.images, d.images) and d2.Nt == 4 and d2.F == 5 and d2.C == 1 and d2.P == 14
+    assert d2.N == 2 and d2.Nc == 2 and abs(d2.offset.mean - 90.0) < 1e-4
+    with pytest.raises(TapqirFileNotFoundError):
+        load(tmp_path / "missing")
+
+
+def test_simulated_data_follow_the_generative_law():
+    d = simulate(2, 40, 50, 1, 14, 3, TEST_PARAMS)
+    assert d.images.shape == (40, 50, 1, 14, 14) and torch.equal(d.images, d.images.floor())
+    assert float(d.images.min()) > 90.0  # every pixel above the offset (glimpse_reader.py:407-411)
+    assert int(d.is_ontarget.sum()) == 20 and (d.xy == 6.5).all()
+    z = torch.as_tensor(d.labels["z"]).float()
+    assert abs(float(z.mean()) - 0.15) < 0.04  # pi
+    off = d.images[20:]  # off-target: background 150 + rare non-specific spots, offset 90
+    assert abs(float(off.median()) - 239) < 3
+
+
+def test_param_layout_is_the_reference_parameter_set():
+    lay = ParamLayout(Nt=3, F=4, C=1, K=2, P=14, eps=1e-7)
+    flat = torch.zeros(lay.total)
+    v = lay.views(flat)
+    shapes = {n: tuple(t.shape) for n, t in v.items()}
+    assert shapes["m_probs"] == (2, 3, 4, 1) and shapes["b_loc"] == (3, 4, 1)
+    assert shapes["background_mean_loc"] == (3, 1, 1) and shapes["pi_mean"] == (1, 2) and shapes["pi_size"] == (1, 1)
+    assert set(v) == set(lay.constraints())  # cosmos.py:471-598
+    assert lay.total == 18 * 12 + 2 * 3 + 9
+    lay.set_constrained(flat, {"gain_loc": 5.0, "proximity_size": 100.0, "w_mean": 1.5, "pi_mean": torch.ones(1, 2) / 2})
+    c = lay.constrained(flat)
+    assert abs(float(c["gain_loc"]) - 5) < 1e-5 and abs(float(c["proximity_size"]) - 100) < 1e-3
+    assert torch.allclose(c["w_mean"], torch.full((2, 3, 4, 1), 1.5), atol=1e-6)
+    assert abs(float(flat[lay.slots()["gain_loc"][0]]) - math.log(5)) < 1e-6  # stored unconstrained
+
+
+def _fit_flow(tmp_path, device, lib):
+    d = simulate(2, 4, 6, 1, 14, 0, TEST_PARAMS)
+    save(d, tmp_path)
+    m = cosmos(K=2, device=device)
+    m.load(tmp_path)
+    if lib is not None:
+        m._make_engine(lib=lib)
+    m.init(lr=0.005, nbatch_size=2, fbatch_size=5)
+    assert m.nbatch_size == 2 and m.fbatch_size == 5 and m.iter == 0
+    m.run(3, progress_bar=lambda r: r)
+    assert m.iter == 3 and math.isfinite(m.iter_loss)
+    ck = torch.load(tmp_path / ".tapqir" / "cosmos_model.tpqr", weights_only=False)
+    assert set(ck) == {"iter", "params", "optimizer", "rolling", "convergence_status"}  # model.py:272-282
+    assert set(ck["params"]) == {"params", "constraints"} and "h_loc" in ck["params"]["params"]
+    assert set(ck["optimizer"]["h_loc"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    # a second model resumes from the checkpoint (model.py:173-180)
+    m2 = cosmos(K=2, device=device)
+    m2.load(tmp_path)
+    if lib is not None:
+        m2._make_engine(lib=lib)
+    m2.init(lr=0.005, nbatch_size=2, fbatch_size=5)
+    assert m2.iter == ck["iter"]
+    for n, t in ck["params"]["params"].items():
+        assert torch.allclose(m2.named_params()[n].cpu().reshape(t.shape), t)
+    # non-finite parameters are detected at checkpoint time (model.py:245-250)
+    m2.engine.params[0] = float("nan")
+    m2.iter_loss = 0.0
+    with pytest.raises(ValueError):
+        m2.save_checkpoint()
+    return m
+
+
+def test_fit_checkpoint_resume_host_build(tmp_path):
+    m = _fit_flow(tmp_path, "cpu", load_hostcheck())
+    assert m.m_probs.shape == (2, 4, 6, 1)
+
+
+@pytest.mark.gpu
+def test_fit_checkpoint_resume_and_stats_on_device(tmp_path):
+    m = _fit_flow(tmp_path, "cuda", None)
+    z, t = m.z_probs, m.theta_probs
+    assert z.shape == (4, 6, 1, 2) and t.shape == (2, 4, 6, 1)
+    assert float(z[2:].abs().max()) == 0.0  # off-target rows stay zero (cosmos.py:615-623)
+    assert torch.allclose(z[:2].sum(-1), torch.ones(2, 6, 1, device=z.device), atol=1e-5)
+    m.compute_stats(save_matlab=True)
+    for f in ("cosmos_params.tpqr", "cosmos_summary.csv", "cosmos_params.mat"):
+        assert (tmp_path / f).exists()
+    p = torch.load(tmp_path / "cosmos_params.tpqr", weights_only=False)
+    assert {"gain", "pi", "lamda", "proximity", "background", "height", "width", "x", "y", "m_probs", "z_probs",
+            "theta_probs", "z_map", "p_specific"} <= set(p)  # cosmos.py:711-784
+    assert float(p["gain"]["LL"]) < float(p["gain"]["Mean"]) < float(p["gain"]["UL"])
