@@ -1,0 +1,117 @@
+"""
+Size-independent properties at BASELINE.json's full single-GPU size (cosmos K=2, 400 AOIs x 1000 frames,
+P=14), where the CPU oracle is out of reach:
+
+  * additivity: the ELBO's local part of the full dataset equals the sum over AOI shards (what the
+    data-parallel all-reduce relies on), with identical draws because RNG keys use global unit ids;
+  * the two pixel kernels (lane-per-unit / interleaved / packed vs 16-lanes-per-unit / LDS-tiled) agree
+    on every unit's outputs;
+  * exchangeability: swapping the two spots' parameters permutes the per-combination log-likelihoods;
+  * a few optimisation steps increase the ELBO and keep every parameter finite.
+"""
+
+import pytest
+import torch
+
+from tapqir_amd.models.cosmos import initial_values
+from tapqir_amd.models.engine import CosmosEngine
+from tapqir_amd.parallel import shard_dataset
+from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+pytestmark = pytest.mark.gpu
+
+N, F, K, P = 400, 1000, 2, 14
+
+
+@pytest.fixture(scope="module")
+def data():
+    class M:
+        K, device = 2, torch.device("cuda", 0)
+
+    return simulate(M, N, F, 1, P, seed=5, params=TEST_PARAMS)
+
+
+def _engine(d, **kw):
+    eng = CosmosEngine(d, K=K, device="cuda:0", seed=21, **kw)
+    eng.layout.set_constrained(eng.params, initial_values(eng, d))
+    return eng
+
+
+def _elbo_stages(eng):
+    a = eng.make_args()
+    for st in ("cosmos_sample_globals", "cosmos_sample_locals", "cosmos_elbo_grads", "cosmos_globals_grad"):
+        eng.call(st, a)
+    torch.cuda.synchronize()
+    return eng.gsum.clone(), float(eng.elbo_out[0])
+
+
+def test_elbo_is_additive_over_aoi_shards(data):
+    full = _engine(data)
+    gs_full, elbo_full = _elbo_stages(full)
+    parts = []
+    for r in range(4):
+        sub, off, Ntg = shard_dataset(data, r, 4)
+        eng = _engine(sub, n_offset=off, Nt_global=Ntg)
+        # the shard's parameters are the matching slice of the full buffer
+        fv, sv = full.named("params"), eng.named("params")
+        hi = off + sub.images.shape[0]
+        for n in sv:
+            sv[n].copy_(fv[n][:, off:hi] if sv[n].dim() == 4 else (fv[n][off:hi] if sv[n].dim() == 3 else fv[n]))
+        gs, _ = _elbo_stages(eng)
+        parts.append(gs)
+        # same draws: global unit ids key the Philox streams
+        B = sub.images.shape[0] * F
+        lo = off * F
+        assert torch.equal(eng.lat.view(-1, B)[:, :1000], full.lat.view(-1, N * F)[:, lo:lo + 1000])
+    total = torch.stack(parts).sum(0)
+    assert torch.allclose(total, gs_full, rtol=2e-6, atol=2e-2), (total, gs_full)
+    assert abs(float(total[2]) - float(gs_full[2])) <= 1e-7 * abs(float(gs_full[2]))
+
+
+def test_pixel_kernels_agree_at_full_size(data):
+    outs = []
+    for il in (1, 1 << 30):
+        eng = _engine(data)
+        eng.il_min_units = il
+        _elbo_stages(eng)
+        outs.append(eng.pix.view(-1, N * F).clone())
+    a, b = outs
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = b.abs().amax(1, keepdim=True).clamp(min=1e-20)
+    assert float(((a - b).abs() / scale).max()) < 5e-5
+    # checksums of the log-likelihood rows agree to fp32 summation accuracy
+    assert torch.allclose(a[:4].double().sum(1), b[:4].double().sum(1), rtol=1e-7)
+
+
+def test_spot_exchangeability(data):
+    eng = _engine(data)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    v = eng.named("params")
+    for n in ("h_loc", "w_mean", "x_mean", "y_mean", "m_probs"):
+        v[n].add_(0.3 * torch.randn(v[n].shape, generator=g, device="cuda"))
+    _elbo_stages(eng)
+    B = N * F
+    lat0 = eng.lat.view(-1, B).clone()
+    ll0 = eng.pix.view(-1, B)[:4].clone()
+    # swap spot 0 <-> spot 1 in the latent draws and re-run only the pixel stage with the same draws
+    lat = eng.lat.view(-1, B)
+    for base in (1, 3, 5, 7):  # rows: h[0],h[1] | w | x | y
+        lat[[base, base + 1]] = lat0[[base + 1, base]]
+    a = eng.make_args(draw_globals=False)
+    eng.call("cosmos_elbo_grads", a)
+    torch.cuda.synchronize()
+    ll1 = eng.pix.view(-1, B)[:4]
+    perm = [0, 2, 1, 3]  # combination index bit k = m_k
+    assert torch.allclose(ll1, ll0[perm], rtol=2e-6, atol=1e-3)
+
+
+def test_steps_improve_the_elbo_and_stay_finite(data):
+    eng = _engine(data)
+    elbos = []
+    for it in range(30):
+        eng.step()
+        if it % 10 == 9 or it == 0:
+            torch.cuda.synchronize()
+            elbos.append(float(eng.elbo_out[0]))
+    assert torch.isfinite(eng.params).all() and torch.isfinite(eng.exp_avg_sq).all()
+    assert elbos[-1] > elbos[0], elbos
