@@ -203,6 +203,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     units_per_step = world * N * F
     value = units_per_step / (dt / args.steps)
+    eng.join()
     elbo = float(eng.elbo_out[0])
     assert torch.isfinite(eng.params).all(), "non-finite parameters after the timed steps"
 
@@ -241,7 +242,7 @@ def main():
         ach = N * F * bpu / t_fb / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": "tq_ksmogn_kernel<K,one_offset,bwd> (fused render + log-prob + pathwise grads)",
+                           "kernel": "tq_ksmogn_il2_kernel<K,P,bwd> (fused render + log-prob + pathwise grads; packed lane-per-unit)",
                            "bytes_per_unit": bpu, "units_per_launch": N * F, "avg_launch_ms": t_fb * 1e3,
                            "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": N * F * bpu / t_f / 1e9,
                                             "frac": N * F * bpu / t_f / 1e9 / HBM_PEAK_GBS},

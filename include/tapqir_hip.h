@@ -173,6 +173,11 @@ typedef struct {
   int32_t fuse_adam;           /* 1 (full batch only): tq_cosmos_elbo_grads applies Adam to the local parameters of
                                   each unit right where their gradient is formed (no gradient round trip through
                                   HBM) and tq_cosmos_adam then updates only the per-AOI and global tail */
+  int32_t overlap_globals;     /* tq_cosmos_step with fuse_adam: run the single-workgroup global work (cross-unit sums,
+                                  global sites, Adam of the per-AOI/global tail, next step's global draws) on a side
+                                  HIP stream of the library, concurrently with the next step's local guide sampling.
+                                  Results (elbo_out, global parameters) are then complete on `stream` only after
+                                  tq_cosmos_join(stream) or a device synchronisation */
   /* RNG */
   uint64_t seed;
   uint32_t step;
@@ -198,6 +203,8 @@ int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream);
 int tq_cosmos_adam(const tq_cosmos_args* a, void* stream);
 /* all of the above back to back */
 int tq_cosmos_step(const tq_cosmos_args* a, void* stream);
+/* make `stream` wait for the library's side stream (see overlap_globals) */
+int tq_cosmos_join(void* stream);
 
 
 /* ---------------------------------------------------------------------------------------

@@ -128,30 +128,41 @@ __global__ __launch_bounds__(256) void tq_adam_kernel(const tq_cosmos_args a, co
 
 // single-GPU step: finish of the cross-unit sums + all global sites + total ELBO in ONE workgroup of 4 waves
 // (one wave per SIMD, so the fp64 site code keeps the full register file); sites are taken round-robin
+__device__ __forceinline__ double tq_wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
-  __shared__ double s_red[256];
+  __shared__ double s_w[4][TQ_MAX_NGSUM];
   __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
   const int nq = 3 + 3 * a.C;
-  for (int j = 0; j < nq; ++j) {
-    double s = 0.0;
-    for (int64_t r = threadIdx.x; r < nblk; r += 256) s += (double)a.blk_part[r * nq + j];
-    if (j == TQ_GS_ELBO) {
-      const int nac = a.nb * a.C;
-      for (int r = threadIdx.x; r < nac; r += 256) s += (double)a.aoi_part[2 * B + r];
-    }
-    s_red[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) a.gsum[j] = s_red[0];
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // every thread walks the rows once, carrying all columns (nq <= 15); then shuffle + 4-way LDS sum
+  double acc[TQ_MAX_NGSUM];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
+  for (int64_t r = threadIdx.x; r < nblk; r += 256) {
+#pragma unroll
+    for (int j = 0; j < TQ_MAX_NGSUM; ++j)
+      if (j < nq) acc[j] += (double)a.blk_part[r * nq + j];
   }
+  const int nac = a.nb * a.C;
+  for (int r = threadIdx.x; r < nac; r += 256) acc[TQ_GS_ELBO] += (double)a.aoi_part[2 * B + r];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const double s = tq_wave_sum_d(acc[j]);
+      if (lane == 0) s_w[wave][j] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
   __threadfence_block();
+  __syncthreads();
   const int ns = TQ_NGSITES(a.C);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0)
+  if (lane == 0)
     for (int s = wave; s < ns; s += 4) s_e[s] = tq_body_globals_grad(a, s);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -302,19 +313,80 @@ extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {
   return check_launch("tq_adam_kernel");
 }
 
-extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {
-  if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
-  if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
-  if (int rc = elbo_grads_impl(a, stream, false)) return rc;
+// ---- side stream for the single-workgroup global work (overlap_globals) -----------------------------------
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_start = nullptr, g_ev_globals = nullptr, g_ev_local = nullptr, g_ev_side_done = nullptr;
+static bool g_side_used = false;
+
+static int side_init() {
+  if (g_side) return TQ_OK;
+  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&g_ev_start, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g_ev_globals, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g_ev_local, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g_ev_side_done, hipEventDisableTiming) != hipSuccess) {
+    tq_set_error("tq_cosmos_step: cannot create the side stream / events");
+    g_side = nullptr;
+    return TQ_ERR_LAUNCH;
+  }
+  return TQ_OK;
+}
+
+extern "C" int tq_cosmos_join(void* stream) {
+  if (g_side && g_side_used && hipStreamWaitEvent((hipStream_t)stream, g_ev_side_done, 0) != hipSuccess) {
+    tq_set_error("tq_cosmos_join: hipStreamWaitEvent failed");
+    return TQ_ERR_LAUNCH;
+  }
+  return TQ_OK;
+}
+
+static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
   if (!a->grad || !a->gsum || !a->elbo_out) {
     tq_set_error("tq_cosmos_step: NULL required pointer");
     return TQ_ERR_ARG;
   }
   // no all-reduce on this path: sums, global sites and the total ELBO finish in one launch
   const int64_t B = tq_batch_units(*a);
-  hipLaunchKernelGGL(tq_reduce_globals_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, tq_cosmos_nblk(B), B);
-  if (int rc = check_launch("tq_reduce_globals_kernel")) return rc;
-  return tq_cosmos_adam(a, stream);
+  hipLaunchKernelGGL(tq_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a, tq_cosmos_nblk(B), B);
+  return check_launch("tq_reduce_globals_kernel");
+}
+
+extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "step")) return rc;
+  hipStream_t main = (hipStream_t)stream;
+  if (!(a->overlap_globals && a->fuse_adam)) {
+    // serial: everything on the caller's stream (after any earlier overlapped step has drained)
+    if (int rc = tq_cosmos_join(stream)) return rc;
+    if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
+    if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
+    if (int rc = elbo_grads_impl(a, stream, false)) return rc;
+    if (int rc = launch_reduce_globals(a, main)) return rc;
+    return tq_cosmos_adam(a, stream);
+  }
+  // Overlapped (full batch, local Adam fused into the unit kernel).  The chain
+  //     cross-unit sums -> global sites -> Adam of the per-AOI/global tail -> next step's global draws
+  // is a few single-workgroup launches (~50 us of one CU); it runs on the side stream while the main
+  // stream already samples the NEXT step's local guide sites (which read local parameters only):
+  //   side: [wait start] sample_globals(t) ............................ [wait local(t)] sums+globals(t), tail Adam(t)
+  //   main: site(t) [wait globals(t)] pixel(t) unit(t) aoi(t) [local(t)] ... next call: site(t+1)
+  if (int rc = side_init()) return rc;
+  g_side_used = true;
+  // whatever the host queued on `stream` before this call (parameter loads, the previous step) comes first
+  if (hipEventRecord(g_ev_start, main) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_start, 0) != hipSuccess) {
+    tq_set_error("tq_cosmos_step: event record/wait failed");
+    return TQ_ERR_LAUNCH;
+  }
+  if (int rc = tq_cosmos_sample_globals(a, (void*)g_side)) return rc;
+  hipEventRecord(g_ev_globals, g_side);
+  if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
+  hipStreamWaitEvent(main, g_ev_globals, 0);
+  if (int rc = elbo_grads_impl(a, stream, false)) return rc;
+  hipEventRecord(g_ev_local, main);
+  hipStreamWaitEvent(g_side, g_ev_local, 0);
+  if (int rc = launch_reduce_globals(a, g_side)) return rc;
+  if (int rc = tq_cosmos_adam(a, (void*)g_side)) return rc;
+  hipEventRecord(g_ev_side_done, g_side);
+  return TQ_OK;
 }
 
 // ---- posterior read-out (cosmos.compute_probs) -------------------------------------------------------------

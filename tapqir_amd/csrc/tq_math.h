@@ -282,16 +282,18 @@ TQ_HD void tq_lgamma_digamma(float a, float* lg, float* dg) {
 
 // double-precision versions (host-side globals math and the mid-range Beta gradient)
 TQ_HD_NOINLINE void tq_lgamma_digamma_d(double a, double* lg, double* dg) {
-  double shift_l = 0.0, shift_d = 0.0;
-  while (a < 12.0) {
-    shift_l += log(a);
-    shift_d += 1.0 / a;
+  // shift up to a >= 12 with  lgamma(a) = lgamma(a+n) - ln prod (a+i),  digamma(a) = digamma(a+n) - sum 1/(a+i):
+  // one logarithm of the running product instead of one per step
+  double prod = 1.0, shift_d = 0.0;
+  for (int it = 0; it < 12 && a < 12.0; ++it) {
+    prod *= a;
+    shift_d += tq_drcp(a);
     a += 1.0;
   }
-  const double ra = 1.0 / a, r2 = ra * ra, lna = log(a);
+  const double ra = tq_drcp(a), r2 = ra * ra, lna = tq_dlog(a);
   const double S = ra * (1.0 / 12.0 + r2 * (-1.0 / 360.0 + r2 * (1.0 / 1260.0 + r2 * (-1.0 / 1680.0 + r2 * (1.0 / 1188.0)))));
   const double dS = r2 * (-1.0 / 12.0 + r2 * (1.0 / 120.0 + r2 * (-1.0 / 252.0 + r2 * (1.0 / 240.0 + r2 * (-1.0 / 132.0)))));
-  *lg = (a - 0.5) * lna - a + 0.91893853320467274178 + S - shift_l;
+  *lg = (a - 0.5) * lna - a + 0.91893853320467274178 + S - tq_dlog(prod);
   *dg = lna - 0.5 * ra + dS - shift_d;
 }
 

@@ -143,6 +143,7 @@ class cosmos(Model):
         self._probs = None
 
     def last_loss(self) -> float:
+        self.engine.join()
         return -float(self.engine.elbo_out.item())
 
     def step(self) -> float:

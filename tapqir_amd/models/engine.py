@@ -11,6 +11,7 @@ tapqir/utils/dataset.py:140-151) and the step workspace.  All arithmetic happens
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -106,6 +107,10 @@ class CosmosEngine:
         # contiguous batches at least this large use the lane-per-unit pixel kernel (64 units per wave):
         # 65536 units = one wave per SIMD of an MI355X
         self.il_min_units = 65536
+        # full-batch steps can run the single-workgroup global work on the library's side stream (see
+        # include/tapqir_hip.h: overlap_globals).  Measured on MI355X at the c2 size the ~50 us it hides are
+        # given back by the two cross-queue event waits per step (~10 us each), so it is opt-in.
+        self.overlap_globals = os.environ.get("TAPQIR_AMD_OVERLAP", "0") == "1"
 
     # -- workspace ---------------------------------------------------------------------------------
     def _workspace(self, nb, fb):
@@ -184,6 +189,7 @@ class CosmosEngine:
         """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``)."""
         a = self.make_args(ndx, fdx)
         a.fuse_adam = int(not a.zero_grad)  # full batch: Adam on the local block is fused into the unit kernel
+        a.overlap_globals = int(self.overlap_globals and allreduce is None and not self._hostcheck)
         if allreduce is None and not self._hostcheck:
             self.call("cosmos_step", a)
         else:
@@ -196,6 +202,12 @@ class CosmosEngine:
             self.call("cosmos_adam", a)
         self.adam_step += 1
 
+    def join(self):
+        """Make the current stream wait for the library's side stream (overlapped global work)."""
+        if not self._hostcheck:
+            _lib.check(self.lib.tq_cosmos_join(self._stream()), "tq_cosmos_join")
+
     # -- named views -----------------------------------------------------------------------------------
     def named(self, which="params"):
+        self.join()  # reads that follow on the current stream see the side stream's updates
         return self.layout.views(getattr(self, which))

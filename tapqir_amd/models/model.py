@@ -192,6 +192,7 @@ class Model:
 
     def save_checkpoint(self, writer=None):
         eng = self.engine
+        eng.join()
         # save only if no NaN values (model.py:245-250)
         if not bool(torch.isfinite(eng.params).all()):
             for k, v in self.named_params().items():

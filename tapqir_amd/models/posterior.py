@@ -46,6 +46,7 @@ def run_probs(eng, a):
 def compute_probs(model, particles=50):
     """cosmos.compute_probs (cosmos.py:609-672): 50 joint guide draws per unit."""
     eng = model.engine
+    eng.join()
     a, ws = probs_args(eng, particles, seed=eng.seed + 0x5EED)
     run_probs(eng, a)
     return ws["z_probs"], ws["theta_probs"]
