@@ -21,6 +21,8 @@
 // vs the quarter-rate transcendental pipe -- see DESIGN.md.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/tapqir_hip.h"
 #include "tq_pixel.h"
 
@@ -542,67 +544,93 @@ __device__ __forceinline__ tq_f2 tq2_rcp(tq_f2 a) { return (tq_f2){__builtin_amd
 __device__ __forceinline__ tq_f2 tq2_log2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)}; }
 __device__ __forceinline__ tq_f2 tq2_exp2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
 
-template <int K>
+// Running sums of the packed loop.  COLACC: the x-moments are kept as per-COLUMN sums (one fma per pixel pair
+// and spot instead of three) and folded with the column coordinates once per unit; used when the K*P/2
+// extra float2 registers fit.
+template <int K, int P, bool COLACC>
 struct TqPixAcc2 {
-  tq_f2 ll[1 << K], sl[1 << K], sS[1 << K];
+  tq_f2 T[1 << K];                       // sum over pixels of (alpha - 1/2) ln(v/mu) - S(alpha)
   tq_f2 acc_b;
-  tq_f2 S0[K], Sx[K], Sy[K], Sr[K], SN[K];
+  tq_f2 S0r[K];                          // sum of q*spot over the current row
+  tq_f2 S0[K], Sy[K], Syy[K];            // per-row folds: sum S0r * {1, j, j^2}
+  tq_f2 Sx[K], Sxx[K];                   // !COLACC: sum q*spot*{i, i^2}
+  tq_f2 col[COLACC ? K : 1][COLACC ? P / 2 : 1];  // COLACC: sum over rows of q*spot per column pair
 };
 
-// one pair of horizontally adjacent pixels (columns ic, ic+1 of row fj), single offset, alpha >= TQ_FAST_ALPHA (two Binet terms)
-template <int K, bool BWD>
-__device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K>& A, tq_f2 v, float b, const tq_f2* spot, const float* W,
-                                              tq_f2 fic, float fj, tq_f2 r2, float g) {
+// per-unit constants of the fast (alpha >= TQ_FAST_ALPHA, two Binet terms) single-offset pixel:
+//   S(alpha)    = r (g/12 - g^3/360 r^2),                      r = 1/mu, alpha = mu/g
+//   da / ln2    = log2(v/mu) + r (g/2 + r (g^2/12 - g^4/120 r^2)) / ln2
+struct TqFastConst {
+  float ca, cb, s1, s3, d1, d2, d4;  // ca = ln2 / g, cb = ln2 / 2: (alpha - 1/2) ln(v/mu) = (ca mu - cb) log2(v/mu)
+};
+
+// one pair of horizontally adjacent pixels (column pair ip of the current row), single offset, fast alpha
+template <int K, int P, bool BWD, bool COLACC>
+__device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 v, float b, const tq_f2* spot,
+                                              const float* W, const int ip, const bool first_in_row,
+                                              const TqFastConst& c) {
   constexpr int M = 1 << K;
   tq_f2 da[M];
+  tq_f2 mus[M];
+  mus[0] = tq2(b);
 #pragma unroll
   for (int mi = 1; mi < M; ++mi) {
-    tq_f2 mu = tq2(b);
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-      if ((mi >> k) & 1) mu += spot[k];
-    const tq_f2 rmu = tq2_rcp(mu);
-    const tq_f2 ra = g * rmu;
-    const tq_f2 l2 = tq2_log2(v * rmu);
-    const tq_f2 rr = ra * ra;
-    A.ll[mi] += mu * l2;
-    A.sl[mi] += l2;
-    A.sS[mi] += ra * (1.0f / 12.0f - rr * (1.0f / 360.0f));
-    if (BWD) da[mi] = l2 * TQ_LN2 + (0.5f * ra + rr * (1.0f / 12.0f - rr * (1.0f / 120.0f)));
+    // mu(m) = mu(m without its highest spot) + that spot: one packed add per combination
+    const int hi = 31 - __builtin_clz(mi);
+    mus[mi] = mus[mi & ~(1 << hi)] + spot[hi];
+    const tq_f2 r = tq2_rcp(mus[mi]);
+    const tq_f2 l2 = tq2_log2(v * r);
+    const tq_f2 u = r * r;
+    A.T[mi] += (mus[mi] * c.ca - c.cb) * l2;
+    A.T[mi] -= r * (u * c.s3 + c.s1);
+    if (BWD) da[mi] = r * (r * (u * c.d4 + c.d2) + c.d1) + l2;  // = da / ln2
   }
   if (BWD) {
+    // q_k = sum_{m containing k} W_m da_m,  acc_b += sum_m W_m da_m
     tq_f2 q[K];
+    if (K == 2) {
+      const tq_f2 t3 = W[3] * da[3];
+      q[0] = W[1] * da[1] + t3;
+      q[1] = W[2] * da[2] + t3;
+      A.acc_b += q[0];
+      A.acc_b += W[2] * da[2];
+    } else {
 #pragma unroll
-    for (int k = 0; k < K; ++k) q[k] = tq2(0.0f);
+      for (int k = 0; k < K; ++k) q[k] = tq2(0.0f);
 #pragma unroll
-    for (int mi = 1; mi < M; ++mi) {
-      const tq_f2 cw = W[mi] * da[mi];
-      A.acc_b += cw;
+      for (int mi = 1; mi < M; ++mi) {
+        const tq_f2 cw = W[mi] * da[mi];
+        A.acc_b += cw;
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        if ((mi >> k) & 1) q[k] += cw;
+        for (int k = 0; k < K; ++k)
+          if ((mi >> k) & 1) q[k] += cw;
+      }
     }
+    const tq_f2 fic = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)};
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const tq_f2 aq = q[k] * spot[k];
-      A.S0[k] += aq;
-      A.Sx[k] += aq * fic;
-      A.Sy[k] += aq * fj;
-      A.Sr[k] += aq * r2;
+      if (COLACC) {
+        A.col[k][ip] += q[k] * spot[k];
+        A.S0r[k] = first_in_row ? q[k] * spot[k] : A.S0r[k] + q[k] * spot[k];
+      } else {
+        const tq_f2 aq = q[k] * spot[k];
+        A.S0r[k] = first_in_row ? aq : A.S0r[k] + aq;
+        A.Sx[k] += aq * fic;
+        A.Sxx[k] += aq * (fic * fic);
+      }
     }
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k) A.SN[k] += spot[k];
 }
 
 template <int K, int P, bool BWD>
-__global__ __launch_bounds__(256) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
+__global__ __launch_bounds__(256, (K <= 2 ? 2 : 1)) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
   static_assert(P % 2 == 0 && (P * P) % 4 == 0, "packed kernel needs an even tile side");
   constexpr int M = 1 << K;
   constexpr int R = ((P / 2) % 2) ? 2 : 1;  // rows per loop body so that the body starts on a float4 boundary
   constexpr int G = R * P / 4;              // float4 groups per body
   constexpr int NB = P / R;                 // bodies per tile
   constexpr int npix = P * P, npix4 = npix / 4;
+  constexpr bool COLACC = BWD && (K * P <= 28);
   const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i_raw < B;
   const int64_t i = live ? i_raw : (B - 1);
@@ -632,66 +660,115 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il2_kernel(const tq_ksmogn_args
   TqPixAcc<K> S;
   tq_acc_zero<K>(S);
   if (__all(b * rg >= TQ_FAST_ALPHA)) {
-    TqPixAcc2<K> A;
-  #pragma unroll
-    for (int mi = 0; mi < M; ++mi) A.ll[mi] = A.sl[mi] = A.sS[mi] = tq2(0.0f);
+    // the x-factor of a spot does not depend on the row: P values per spot, kept in registers
+    tq_f2 ex[K][P / 2];
+    float sum_ex[K], sum_gy[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      tq_f2 acc = tq2(0.0f);
+#pragma unroll
+      for (int ip = 0; ip < P / 2; ++ip) {
+        const tq_f2 dx = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)} - cx[k];
+        ex[k][ip] = tq2_exp2(dx * dx * nl2[k]);
+        acc += ex[k][ip];
+      }
+      sum_ex[k] = acc.x + acc.y;
+      sum_gy[k] = 0.0f;
+    }
+    TqFastConst c;
+    {
+      const float g2 = g * g, rl2 = 1.0f / TQ_LN2;
+      c.ca = TQ_LN2 * rg;
+      c.cb = 0.5f * TQ_LN2;
+      c.s1 = g * (1.0f / 12.0f);
+      c.s3 = -g2 * g * (1.0f / 360.0f);
+      c.d1 = 0.5f * g * rl2;
+      c.d2 = g2 * (1.0f / 12.0f) * rl2;
+      c.d4 = -g2 * g2 * (1.0f / 120.0f) * rl2;
+    }
+    TqPixAcc2<K, P, COLACC> A;
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) A.T[mi] = tq2(0.0f);
     A.acc_b = tq2(0.0f);
-  #pragma unroll
-    for (int k = 0; k < K; ++k) A.S0[k] = A.Sx[k] = A.Sy[k] = A.Sr[k] = A.SN[k] = tq2(0.0f);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      A.S0r[k] = A.S0[k] = A.Sy[k] = A.Syy[k] = A.Sx[k] = A.Sxx[k] = tq2(0.0f);
+      if (COLACC) {
+#pragma unroll
+        for (int ip = 0; ip < P / 2; ++ip) A.col[k][ip] = tq2(0.0f);
+      }
+    }
 
     float4 ring[G];
-  #pragma unroll
+#pragma unroll
     for (int j = 0; j < G; ++j) ring[j] = src[j * 64];
-    for (int body = 0; body < NB; ++body) {
+    // one loop body = R rows; MORE: the groups of the next body are fetched as those of this one retire
+    // (the last body is peeled so that the prefetches are unconditional and stay where they are written)
+    auto run_body = [&](const int body, auto more_tag) {
+      constexpr bool MORE = decltype(more_tag)::value;
       const float4* nxt = src + (int64_t)(body + 1) * G * 64;
-      const bool more = body + 1 < NB;
-  #pragma unroll
+#pragma unroll
       for (int rr = 0; rr < R; ++rr) {
         const float fj = (float)(body * R + rr);
         float agy[K];
-  #pragma unroll
+#pragma unroll
         for (int k = 0; k < K; ++k) {
           const float dy = fj - cy[k];
           agy[k] = amph[k] * __builtin_amdgcn_exp2f(dy * dy * nl2[k]);
+          sum_gy[k] += agy[k];
         }
-        const float fj2 = fj * fj;
-  #pragma unroll
+#pragma unroll
         for (int ip = 0; ip < P / 2; ++ip) {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int pair = rr * (P / 2) + ip;  // pair index within the body (compile-time after unrolling)
           const int gi = pair >> 1;            // float4 group within the body
           const float4 d4 = ring[gi];
           const tq_f2 D = (pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y};
-          if ((pair & 1) && more) ring[gi] = nxt[gi * 64];  // group consumed: fetch the next body's
-          const tq_f2 fic = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)};
-          const tq_f2 r2 = fic * fic + fj2;
+          if (MORE && (pair & 1)) ring[gi] = nxt[gi * 64];  // group consumed: fetch the next body's
           tq_f2 spot[K];
-  #pragma unroll
+#pragma unroll
+          for (int k = 0; k < K; ++k) spot[k] = agy[k] * ex[k][ip];
+          tq_pixel_pair<K, P, BWD, COLACC>(A, D - off0, b, spot, W, ip, ip == 0, c);
+        }
+        if (BWD) {
+          const float fj2 = fj * fj;
+#pragma unroll
           for (int k = 0; k < K; ++k) {
-            const tq_f2 dx = fic - cx[k];
-            spot[k] = agy[k] * tq2_exp2(dx * dx * nl2[k]);
+            if (!COLACC) A.S0[k] += A.S0r[k];
+            A.Sy[k] += A.S0r[k] * fj;
+            A.Syy[k] += A.S0r[k] * fj2;
           }
-          tq_pixel_pair<K, BWD>(A, D - off0, b, spot, W, fic, fj, r2, g);
         }
       }
-    }
+    };
+#pragma unroll 1
+    for (int body = 0; body < NB - 1; ++body) run_body(body, std::true_type{});
+    run_body(NB - 1, std::false_type{});
 
     // fold the two pixel slots, then the common single-offset assembly / store
-  #pragma unroll
-    for (int mi = 1; mi < M; ++mi) {
-      S.ll[mi] = A.ll[mi].x + A.ll[mi].y;
-      S.sl[mi] = A.sl[mi].x + A.sl[mi].y;
-      S.sS[mi] = A.sS[mi].x + A.sS[mi].y;
-    }
-    S.acc_b = A.acc_b.x + A.acc_b.y;
-  #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      S.S0[k] = A.S0[k].x + A.S0[k].y;
-      S.Sx[k] = A.Sx[k].x + A.Sx[k].y;
-      S.Sy[k] = A.Sy[k].x + A.Sy[k].y;
-      S.Sr[k] = A.Sr[k].x + A.Sr[k].y;
-      S.SN[k] = A.SN[k].x + A.SN[k].y;
+#pragma unroll
+    for (int mi = 1; mi < M; ++mi) S.sS[mi] = -(A.T[mi].x + A.T[mi].y);  // the assembly adds -sS; ll = sl = 0
+#pragma unroll
+    for (int k = 0; k < K; ++k) S.SN[k] = sum_ex[k] * sum_gy[k];  // sum over the tile of a separable spot
+    if (BWD) {
+      S.acc_b = (A.acc_b.x + A.acc_b.y) * TQ_LN2;  // da was carried in units of ln 2
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        tq_f2 s0 = A.S0[k], sx = A.Sx[k], sxx = A.Sxx[k];
+        if (COLACC) {
+          s0 = sx = sxx = tq2(0.0f);
+#pragma unroll
+          for (int ip = 0; ip < P / 2; ++ip) {
+            const tq_f2 fic = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)};
+            s0 += A.col[k][ip];
+            sx += A.col[k][ip] * fic;
+            sxx += A.col[k][ip] * (fic * fic);
+          }
+        }
+        S.S0[k] = (s0.x + s0.y) * TQ_LN2;
+        S.Sx[k] = (sx.x + sx.y) * TQ_LN2;
+        S.Sy[k] = (A.Sy[k].x + A.Sy[k].y) * TQ_LN2;
+        S.Sr[k] = (sxx.x + sxx.y + A.Syy[k].x + A.Syy[k].y) * TQ_LN2;
+      }
     }
   } else {
     // some unit of this wave has a small alpha = background / gain: general (scalar, exact Binet) loop
