@@ -114,44 +114,31 @@ __device__ __forceinline__ void tq_pixel_one_offset(TqPixAcc<K>& A, float v, flo
   for (int k = 0; k < K; ++k) A.SN[k] += spot[k];
 }
 
-// One pixel, general path: online log-sum-exp over the offset samples.
+// One pixel, general path (offset histogram, tq_pixel.h).
 template <int K, bool BWD, bool FAST>
-__device__ __forceinline__ void tq_pixel_multi_offset(TqPixAcc<K>& A, const tq_ksmogn_args& a, float D, float ln_g,
-                                                      float b, const float* spot, const float* W, float fic,
-                                                      float fj, float g, float rg) {
+__device__ __forceinline__ void tq_pixel_multi_offset(TqPixAcc<K>& A, const tq_ksmogn_args& a, const TqOffsetInfo& h,
+                                                      float D, float ln_g, float b, const float* spot, const float* W,
+                                                      float fic, float fj, float g, float rg) {
   constexpr int M = 1 << K;
-  TqComboPix cp[M];
-  TqLse acc[M];
+  float mu[M], lp[M], da[M], gq[M];
 #pragma unroll
   for (int mi = 0; mi < M; ++mi) {
-    float mu = b;
+    mu[mi] = b;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      if ((mi >> k) & 1) mu += spot[k];
-    tq_combo_prepare(mu, rg, g, ln_g, &cp[mi]);
-    tq_lse_init(&acc[mi]);
+      if ((mi >> k) & 1) mu[mi] += spot[k];
   }
-  for (int o = 0; o < a.O; ++o) {
-    const float v = D - a.offset_samples[o];
-    if (v > 0.0f) {  // ksmogn.py:226 / KeOps Step(x - g - 1): offsets at or above the pixel are excluded
-      const float lv = TQ_FLOG(v);
-      const float lwl = a.offset_logits[o] - lv;
-#pragma unroll
-      for (int mi = 0; mi < M; ++mi) tq_lse_push(&acc[mi], cp[mi], v, lv, lwl);
-    }
-  }
+  tq_pix_multi_offset<M, BWD, FAST>(D, mu, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, lp, da, gq);
   float q[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) q[k] = 0.0f;
 #pragma unroll
   for (int mi = 0; mi < M; ++mi) {
-    float lp, da, gq;
-    tq_lse_finish<FAST>(acc[mi], cp[mi], rg, &lp, &da, &gq);
-    A.ll[mi] += lp;
+    A.ll[mi] += lp[mi];
     if (BWD) {
-      const float cw = W[mi] * da;
+      const float cw = W[mi] * da[mi];
       A.acc_b += cw;
-      A.acc_g += W[mi] * gq;
+      A.acc_g += W[mi] * gq[mi];
 #pragma unroll
       for (int k = 0; k < K; ++k)
         if ((mi >> k) & 1) q[k] += cw;
@@ -277,6 +264,8 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
                                               float ln_g, const float* W) {
   const uint32_t magic = (1u << 20) / (uint32_t)P + 1u;  // exact pix / P for pix < 4096, P <= 64
   const float off0 = a.offset_samples[0];
+  TqOffsetInfo h;
+  if (!ONE_OFFSET) tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
   for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
     const int j = (int)(((uint32_t)pix * magic) >> 20);
     const int ic = pix - j * P;
@@ -286,7 +275,7 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
 #pragma unroll
     for (int k = 0; k < K; ++k) spot[k] = amph[k] * s_fac[(2 * k) * TQ_MAX_P + ic] * s_fac[(2 * k + 1) * TQ_MAX_P + j];
     if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, D - off0, b, spot, W, fic, fj, g, rg, ln_g);
-    else tq_pixel_multi_offset<K, BWD, FAST>(A, a, D, ln_g, b, spot, W, fic, fj, g, rg);
+    else tq_pixel_multi_offset<K, BWD, FAST>(A, a, h, D, ln_g, b, spot, W, fic, fj, g, rg);
   }
 }
 
@@ -427,6 +416,8 @@ __device__ __forceinline__ void tq_il_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn
                                                  const float* W) {
   const int npix4 = (npix + 3) >> 2;
   const float off0 = a.offset_samples[0];
+  TqOffsetInfo h;
+  if (!ONE_OFFSET) tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
   int ic = 0, jr = 0;  // wave-uniform pixel coordinates
   float fj = 0.0f, agy[K];
 #pragma unroll
@@ -446,7 +437,7 @@ __device__ __forceinline__ void tq_il_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn
           spot[k] = agy[k] * __builtin_amdgcn_exp2f(dx * dx * nl2[k]);
         }
         if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, d4[e] - off0, b, spot, W, fic, fj, g, rg, ln_g);
-        else tq_pixel_multi_offset<K, BWD, FAST>(A, a, d4[e], ln_g, b, spot, W, fic, fj, g, rg);
+        else tq_pixel_multi_offset<K, BWD, FAST>(A, a, h, d4[e], ln_g, b, spot, W, fic, fj, g, rg);
         if (++ic == P) {  // next row: refresh the y-factors
           ic = 0;
           ++jr;
@@ -789,6 +780,231 @@ __global__ __launch_bounds__(256, (K <= 2 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
   }
 }
 
+// =============================================================================================
+// Packed lane-per-unit kernel for an offset HISTOGRAM (O > 1; real data, glimpse_reader.py:414-421).
+// Same mapping as above (one lane per unit, two horizontally adjacent pixels per lane in float2
+// registers); per pixel pair the loop over the offset samples runs the formulation of tq_pixel.h:
+// per (offset, combination) one packed fma, one packed add, two exp2 and three packed accumulations.
+// The per-offset constants (delta_o - delta_min, db_o) are tabulated once per workgroup in LDS and read
+// back as wave-uniform broadcasts.  A pixel pair with masked offsets (some delta_o >= D) anywhere in
+// the wave takes the scalar routine instead.
+// =============================================================================================
+#define TQ_MO_MAX_O 1024
+
+// WFAC: the per-offset factor 2^db_o is pulled out of the exponential (t = 2^db_o * exp2(a dl + c)) and folded
+// into the accumulations as a multiplier, which removes the packed add; valid while |db_o| stays far
+// inside the fp32 exponent range (checked once per kernel from the histogram and the gain).
+// Table entry of offset o: WFAC ? {2^db_o * (delta_o - delta_min), 2^db_o} : {delta_o - delta_min, db_o}.
+template <int K, bool BWD, bool WFAC>
+__device__ __forceinline__ void tq_pair_multi_offset(TqPixAcc<K>& A, const tq_ksmogn_args& a, const TqOffsetInfo& h,
+                                                     const float2* __restrict__ s_tab, const bool fast, tq_f2 D,
+                                                     float b, const tq_f2* spot, const float* W, tq_f2 fic, float fj,
+                                                     float g, float rg, float ln_g) {
+  constexpr int M = 1 << K;
+  tq_f2 mu[M], lp[M], da[M], gq[M];
+  mu[0] = tq2(b);
+#pragma unroll
+  for (int mi = 1; mi < M; ++mi) {
+    const int hi = 31 - __builtin_clz(mi);
+    mu[mi] = mu[mi & ~(1 << hi)] + spot[hi];
+  }
+  const tq_f2 vhi = D - h.dmin;
+  const tq_f2 vlo = D - h.dmax;
+  if (__all(vlo.x > 0.0f && vlo.y > 0.0f)) {
+    // every offset is below both pixels in every lane: no masks
+    const tq_f2 rvhi = tq2_rcp(vhi);
+    tq_f2 av[M], cv[M], vs[M], S0[M], S1[M], S2[M];
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) {
+      const tq_f2 t = mu[mi] - g;
+      vs[mi] = (tq_f2){fminf(fmaxf(t.x, vlo.x), vhi.x), fminf(fmaxf(t.y, vlo.y), vhi.y)};
+      av[mi] = mu[mi] * rg - 1.0f;
+      cv[mi] = -av[mi] * tq2_log2(vs[mi] * rvhi);
+      S0[mi] = S1[mi] = S2[mi] = tq2(0.0f);
+    }
+#pragma unroll 2
+    for (int o = 0; o < a.O; ++o) {
+      const float so = a.offset_samples[o];
+      const float2 tb = s_tab[o];
+      const tq_f2 dl = tq2_log2((D - so) * rvhi);
+      if (WFAC) {
+        const tq_f2 wdl = dl * tb.y;
+#pragma unroll
+        for (int mi = 0; mi < M; ++mi) {
+          const tq_f2 e = tq2_exp2(av[mi] * dl + cv[mi]);
+          S0[mi] += e * tb.y;
+          if (BWD) {
+            S1[mi] += e * wdl;
+            S2[mi] += e * tb.x;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < M; ++mi) {
+          const tq_f2 t = tq2_exp2((av[mi] * dl + cv[mi]) + tb.y);
+          S0[mi] += t;
+          if (BWD) {
+            S1[mi] += t * dl;
+            S2[mi] += t * tb.x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) {
+      float l0, d0, q0, l1, d1, q1;
+      tq_mo_finish(fast, mu[mi].x, vs[mi].x, vhi.x, S0[mi].x, S1[mi].x, S2[mi].x, h, g, rg, ln_g, &l0, &d0, &q0);
+      tq_mo_finish(fast, mu[mi].y, vs[mi].y, vhi.y, S0[mi].y, S1[mi].y, S2[mi].y, h, g, rg, ln_g, &l1, &d1, &q1);
+      lp[mi] = (tq_f2){l0, l1};
+      da[mi] = (tq_f2){d0, d1};
+      gq[mi] = (tq_f2){q0, q1};
+    }
+  } else {
+    float m0[M], m1[M], l0[M], l1[M], d0[M], d1[M], q0[M], q1[M];
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) {
+      m0[mi] = mu[mi].x;
+      m1[mi] = mu[mi].y;
+    }
+    if (fast) {
+      tq_pix_multi_offset<M, BWD, true>(D.x, m0, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, l0, d0, q0);
+      tq_pix_multi_offset<M, BWD, true>(D.y, m1, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, l1, d1, q1);
+    } else {
+      tq_pix_multi_offset<M, BWD, false>(D.x, m0, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, l0, d0, q0);
+      tq_pix_multi_offset<M, BWD, false>(D.y, m1, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, l1, d1, q1);
+    }
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) {
+      lp[mi] = (tq_f2){l0[mi], l1[mi]};
+      da[mi] = (tq_f2){d0[mi], d1[mi]};
+      gq[mi] = (tq_f2){q0[mi], q1[mi]};
+    }
+  }
+  tq_f2 q[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) q[k] = tq2(0.0f);
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) {
+    A.ll[mi] += lp[mi].x + lp[mi].y;
+    if (BWD) {
+      const tq_f2 cw = W[mi] * da[mi];
+      const tq_f2 gw = W[mi] * gq[mi];
+      A.acc_b += cw.x + cw.y;
+      A.acc_g += gw.x + gw.y;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if ((mi >> k) & 1) q[k] += cw;
+    }
+  }
+  if (BWD) {
+    const tq_f2 r2 = fic * fic + fj * fj;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const tq_f2 aq = q[k] * spot[k];
+      const tq_f2 ax = aq * fic, ar = aq * r2;
+      A.S0[k] += aq.x + aq.y;
+      A.Sx[k] += ax.x + ax.y;
+      A.Sy[k] += (aq.x + aq.y) * fj;
+      A.Sr[k] += ar.x + ar.y;
+    }
+  }
+}
+
+template <int K, bool BWD, bool WFAC>
+__device__ __forceinline__ void tq_il2m_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_args& a, const TqOffsetInfo& h,
+                                                   const float2* __restrict__ s_tab, const bool fast,
+                                                   const float4* __restrict__ src, int P, float b, const float* amph,
+                                                   const float* nl2, const float* cx, const float* cy, float g,
+                                                   float rg, float ln_g, const float* W) {
+  const int npix4 = (P * P) >> 2;
+  int ic = 0, jr = 0;  // wave-uniform coordinates of the next pixel pair (P even: a pair never straddles rows)
+  float agy[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) agy[k] = amph[k] * __builtin_amdgcn_exp2f(cy[k] * cy[k] * nl2[k]);
+  float4 cur = src[0];
+  for (int q = 0; q < npix4; ++q) {
+    const float4 d4 = cur;
+    if (q + 1 < npix4) cur = src[(int64_t)(q + 1) * 64];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const tq_f2 D = half ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y};
+      const tq_f2 fic = (tq_f2){(float)ic, (float)(ic + 1)};
+      const float fj = (float)jr;
+      tq_f2 spot[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const tq_f2 dx = fic - cx[k];
+        spot[k] = agy[k] * tq2_exp2(dx * dx * nl2[k]);
+      }
+      tq_pair_multi_offset<K, BWD, WFAC>(A, a, h, s_tab, fast, D, b, spot, W, fic, fj, g, rg, ln_g);
+      ic += 2;
+      if (ic == P) {
+        ic = 0;
+        ++jr;
+        const float fn = (float)jr;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float dy = fn - cy[k];
+          agy[k] = amph[k] * __builtin_amdgcn_exp2f(dy * dy * nl2[k]);
+        }
+      }
+    }
+  }
+}
+
+template <int K, bool BWD>
+__global__ __launch_bounds__(256) void tq_ksmogn_il2m_kernel(const tq_ksmogn_args a, const int64_t B) {
+  constexpr int M = 1 << K;
+  __shared__ float2 s_tab[TQ_MO_MAX_O];
+  const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i_raw < B;
+  const int64_t i = live ? i_raw : (B - 1);
+  const int P = a.P, npix = P * P;
+  const int npix4 = npix >> 2;
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i_raw >> 6) * npix4) * 64 + (i_raw & 63);
+
+  const float g = a.gain[0];
+  const float rg = TQ_FRCP(g);
+  const float ln_g = TQ_FLOG(g);
+  TqOffsetInfo h;
+  tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
+  const float beta2 = rg * TQ_LOG2E;
+  // |db_o| <= max(log2(w_max / w_min), beta2 (delta_max - delta_min)): the factored form needs it well inside +-126
+  const bool wfac = fmaxf(h.lw2max - h.lw2min, beta2 * (h.dmax - h.dmin)) < 40.0f;
+  for (int o = threadIdx.x; o < a.O; o += 256) {
+    const float dd = a.offset_samples[o] - h.dmin;
+    const float db = (a.offset_logits[o] * TQ_LOG2E - h.lw2max) + beta2 * dd;
+    const float w = __builtin_amdgcn_exp2f(db);
+    s_tab[o] = wfac ? make_float2(w * dd, w) : make_float2(dd, db);
+  }
+  __syncthreads();
+
+  const float tx = a.xy[2 * i], ty = a.xy[2 * i + 1];
+  const float b = a.background[i];
+  float hk[K], wk[K], amph[K], nl2[K], cx[K], cy[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    hk[k] = a.height[k * B + i];
+    wk[k] = a.width[k * B + i];
+    cx[k] = a.x[k * B + i] + tx;
+    cy[k] = a.y[k * B + i] + ty;
+    const float inv2v = 0.5f * TQ_FRCP(wk[k] * wk[k]);
+    amph[k] = hk[k] * inv2v * (1.0f / TQ_PI);
+    nl2[k] = -inv2v * 1.44269504088896340736f;
+  }
+  float W[M];
+#pragma unroll
+  for (int mi = 0; mi < M; ++mi) W[mi] = 0.0f;
+  if (BWD) tq_load_weights<K>(a, B, i, i, (int)((uint32_t)i / (uint32_t)(a.F * a.C)), W);
+
+  TqPixAcc<K> A;
+  tq_acc_zero<K>(A);
+  const bool fast = __all(b * rg >= TQ_FAST_ALPHA);
+  if (wfac) tq_il2m_pixel_loop<K, BWD, true>(A, a, h, s_tab, fast, src, P, b, amph, nl2, cx, cy, g, rg, ln_g, W);
+  else tq_il2m_pixel_loop<K, BWD, false>(A, a, h, s_tab, fast, src, P, b, amph, nl2, cx, cy, g, rg, ln_g, W);
+  if (live) tq_pixel_store<K, false, BWD>(a, B, i, A, W, b, rg, hk, wk, cx, cy, (float)npix, 0.0f, false);
+}
+
 // (U, npix) row-major tiles -> the interleaved layout above; out holds ceil(U/64) * npix4 * 256 floats
 __global__ __launch_bounds__(256) void tq_interleave_kernel(const float* __restrict__ images, float* __restrict__ out,
                                                             const int64_t U, const int npix, const int64_t total4) {
@@ -875,6 +1091,11 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
         else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, false>), grid, block, 0, st, a, B);
       }
       return launch_status("tq_ksmogn_il2_kernel");
+    }
+    if (!ONE && (a.P % 2) == 0 && a.O <= TQ_MO_MAX_O) {
+      if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2m_kernel<K, true>), grid, block, 0, st, a, B);
+      else hipLaunchKernelGGL((tq_ksmogn_il2m_kernel<K, false>), grid, block, 0, st, a, B);
+      return launch_status("tq_ksmogn_il2m_kernel");
     }
     if (bwd) hipLaunchKernelGGL((tq_ksmogn_il_kernel<K, ONE, true>), grid, block, 0, st, a, B);
     else hipLaunchKernelGGL((tq_ksmogn_il_kernel<K, ONE, false>), grid, block, 0, st, a, B);

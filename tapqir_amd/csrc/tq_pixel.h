@@ -17,20 +17,6 @@
 #pragma once
 #include "tq_math.h"
 
-// quantities that depend on the combination (alpha) but not on the offset
-struct TqComboPix {
-  float alpha, lnalpha, ralpha;  // alpha, ln alpha, 1/alpha
-  float lmu, rmu;                // ln mu, 1/mu
-};
-
-TQ_HD void tq_combo_prepare(float mu, float rg, float g, float ln_g, TqComboPix* c) {
-  c->rmu = TQ_FRCP(mu);
-  c->lmu = TQ_FLOG(mu);
-  c->alpha = mu * rg;
-  c->lnalpha = c->lmu - ln_g;
-  c->ralpha = g * c->rmu;
-}
-
 // ---- single-offset path (all offset samples identical after host-side merging) -------------------
 // With one offset delta, v = D - delta is a property of the DATA.  Write the per-pixel log-density as
 //   log p = [ln w - ln sqrt(2pi) - ln v] + (1/g) [mu ln(v/mu) + mu - v] + (1/2) [ln v - ln g - ln(v/mu)] - S(alpha)
@@ -87,47 +73,109 @@ TQ_HD void tq_combo0_prepare(float b, float rg, float g, float ln_g, TqCombo0* c
   c->c_da = 0.5f * ra - dS;
 }
 
-// Online log-sum-exp accumulator over offsets for one combination.
-struct TqLse {
-  float m, s, sl, sv;  // running max, sum e, sum e * ln rho_o, sum e * v_o
+// ---- general path: a histogram of offsets ---------------------------------------------------------
+// For one pixel D and one combination (alpha = mu/g, beta = 1/g), with v_o = D - delta_o > 0:
+//   log p = alpha ln beta - lgamma(alpha) + ln sum_o w_o v_o^(alpha-1) exp(-beta v_o).
+// All exponents are taken relative to a reference v_s INSIDE the valid range [v_lo, v_hi] at the maximiser
+// of the (concave, or decreasing when alpha < 1) function (alpha-1) ln v - beta v, v* = mu - g:
+//   v_s = clamp(mu - g, v_lo, v_hi),   v_hi = D - min_o delta_o,   v_lo = smallest positive v_o
+// so that the terms
+//   t_o = exp2[ (alpha-1) (log2(v_o / v_hi) - log2(v_s / v_hi)) + db_o ],
+//   db_o = log2(w_o / w_max) + (beta / ln 2) (delta_o - delta_min)        (a per-offset constant)
+// neither overflow (db_o <= beta (delta_max - delta_min) / ln 2) nor all underflow, and
+//   log p = [ -ln v_s + alpha phi(v_s / mu) + (1/2) ln alpha - ln sqrt(2 pi) - S(alpha) ]     (Binet form, see above)
+//           + ln w_max + beta (v_s - v_hi) + ln sum_o t_o.
+// Per (offset, combination) that is one fma, one add, one exp2 and three accumulations
+// (sum t, sum t log2(v_o / v_hi), sum t (delta_o - delta_min)); the log2 of v_o is shared by the combinations.
+//   d/dalpha = E_t[ln(v_o / mu)] + 1/(2 alpha) - S'(alpha),   E_t[v_o] = v_hi - E_t[delta_o - delta_min].
+struct TqOffsetInfo {
+  float dmin, dmax;      // smallest / largest offset sample
+  float lw2max, lw2min;  // log2 of the largest / smallest weight
 };
-TQ_HD void tq_lse_init(TqLse* a) {
-  a->m = -INFINITY;
-  a->s = 0.0f;
-  a->sl = 0.0f;
-  a->sv = 0.0f;
-}
-// one (offset, combination) term:  t = (ln w_o - ln v_o) + alpha * phi(rho_o)
-TQ_HD void tq_lse_push(TqLse* a, const TqComboPix& c, float v, float lv, float lwl) {
-  const float rho = v * c.rmu;
-  const float lrho = lv - c.lmu;
-  const float t = lwl + c.alpha * (lrho + 1.0f - rho);
-  const float e = TQ_FEXP(-fabsf(t - a->m));  // exp(-inf) = 0 covers the first push
-  if (t > a->m) {
-    a->s = a->s * e + 1.0f;
-    a->sl = a->sl * e + lrho;
-    a->sv = a->sv * e + v;
-    a->m = t;
-  } else {
-    a->s += e;
-    a->sl += e * lrho;
-    a->sv += e * v;
+TQ_HD void tq_offset_info(const float* samples, const float* logits, int O, TqOffsetInfo* h) {
+  float lo = samples[0], hi = samples[0], lw = logits[0], lwn = logits[0];
+  for (int o = 1; o < O; ++o) {
+    lo = fminf(lo, samples[o]);
+    hi = fmaxf(hi, samples[o]);
+    lw = fmaxf(lw, logits[o]);
+    lwn = fminf(lwn, logits[o]);
   }
+  h->dmin = lo;
+  h->dmax = hi;
+  h->lw2max = lw * TQ_LOG2E;
+  h->lw2min = lwn * TQ_LOG2E;
 }
-template <bool FAST>
-TQ_HD void tq_lse_finish(const TqLse& a, const TqComboPix& c, float rg, float* lp, float* da, float* gq) {
-  if (a.s == 0.0f) {  // every offset masked (D <= min offset): log 0
-    *lp = -INFINITY;
-    *da = 0.0f;
-    *gq = 0.0f;
+
+// reference point of one combination: returns v_s, writes a = alpha - 1 and c = -a log2(v_s / v_hi)
+TQ_HD float tq_mo_reference(float mu, float g, float rg, float vlo, float vhi, float rvhi, float* a, float* c) {
+  const float vs = fminf(fmaxf(mu - g, vlo), vhi);
+  *a = mu * rg - 1.0f;
+  *c = -(*a) * TQ_FLOG2(vs * rvhi);
+  return vs;
+}
+
+// S0 = sum t, S1 = sum t log2(v_o / v_hi), S2 = sum t (delta_o - delta_min)  ->  log p, d/dalpha, gain term
+TQ_HD void tq_mo_finish(bool fast, float mu, float vs, float vhi, float S0, float S1, float S2, const TqOffsetInfo& h,
+                        float g, float rg, float ln_g, float* lp, float* da, float* gq) {
+  const float rmu = TQ_FRCP(mu);
+  const float alpha = mu * rg, ralpha = g * rmu;
+  const float lnalpha = TQ_FLOG(mu) - ln_g;
+  float S, dS;
+  if (fast) tq_binet_fast(ralpha, &S, &dS);  // alpha >= TQ_FAST_ALPHA (the caller's test is wave-uniform on the device)
+  else tq_binet(alpha, lnalpha, ralpha, &S, &dS);
+  const float rho = vs * rmu;
+  const float lrho = TQ_FLOG(rho);
+  const float rs = TQ_FRCP(S0);
+  *lp = (alpha * (lrho + 1.0f - rho) - (lrho + TQ_FLOG(mu))) + 0.5f * lnalpha - TQ_LN_SQRT_2PI - S
+        + h.lw2max * TQ_LN2 + rg * (vs - vhi) + TQ_LN2 * TQ_FLOG2(S0);
+  const float d = TQ_LN2 * (S1 * rs + TQ_FLOG2(vhi * rmu)) + 0.5f * ralpha - dS;
+  *da = d;
+  *gq = alpha * (d + 1.0f) - (vhi - S2 * rs) * rg;
+}
+
+// One pixel, every combination (scalar form; the packed kernel in tq_ksmogn.hip repeats it on float2).
+template <int M, bool BWD, bool FAST>
+TQ_HD void tq_pix_multi_offset(float D, const float* mu, const float* samples, const float* logits, int O,
+                               const TqOffsetInfo& h, float g, float rg, float ln_g, float* lp, float* da, float* gq) {
+  const float vhi = D - h.dmin;
+  if (!(vhi > 0.0f)) {  // every offset at or above the pixel (ksmogn.py:226): log 0, no gradient
+    for (int mi = 0; mi < M; ++mi) {
+      lp[mi] = -INFINITY;
+      da[mi] = 0.0f;
+      gq[mi] = 0.0f;
+    }
     return;
   }
-  float S, dS;
-  if (FAST) tq_binet_fast(c.ralpha, &S, &dS);
-  else tq_binet(c.alpha, c.lnalpha, c.ralpha, &S, &dS);
-  const float rs = TQ_FRCP(a.s);
-  *lp = a.m + TQ_FLOG(a.s) + 0.5f * c.lnalpha - TQ_LN_SQRT_2PI - S;
-  const float d = a.sl * rs + 0.5f * c.ralpha - dS;
-  *da = d;
-  *gq = c.alpha * (d + 1.0f) - a.sv * rs * rg;
+  float vlo = D - h.dmax;
+  if (!(vlo > 0.0f)) {  // some offsets are masked: the smallest valid v
+    vlo = vhi;
+    for (int o = 0; o < O; ++o) {
+      const float v = D - samples[o];
+      if (v > 0.0f) vlo = fminf(vlo, v);
+    }
+  }
+  const float rvhi = TQ_FRCP(vhi);
+  const float beta2 = rg * TQ_LOG2E;
+  float a[M], c[M], vs[M], S0[M], S1[M], S2[M];
+  for (int mi = 0; mi < M; ++mi) {
+    vs[mi] = tq_mo_reference(mu[mi], g, rg, vlo, vhi, rvhi, &a[mi], &c[mi]);
+    S0[mi] = S1[mi] = S2[mi] = 0.0f;
+  }
+  for (int o = 0; o < O; ++o) {
+    const float v = D - samples[o];
+    if (v > 0.0f) {
+      const float dl = TQ_FLOG2(v * rvhi);
+      const float dd = samples[o] - h.dmin;
+      const float db = (logits[o] * TQ_LOG2E - h.lw2max) + beta2 * dd;
+      for (int mi = 0; mi < M; ++mi) {
+        const float t = TQ_FEXP2((a[mi] * dl + c[mi]) + db);
+        S0[mi] += t;
+        if (BWD) {
+          S1[mi] += t * dl;
+          S2[mi] += t * dd;
+        }
+      }
+    }
+  }
+  for (int mi = 0; mi < M; ++mi) tq_mo_finish(FAST, mu[mi], vs[mi], vhi, S0[mi], S1[mi], S2[mi], h, g, rg, ln_g, &lp[mi], &da[mi], &gq[mi]);
 }

@@ -65,6 +65,15 @@ def make_dataset(N=4, F=6, C=1, P=14, K=2, seed=0, offsets="sim", mask=None):
         w = torch.exp(-0.5 * ((s - 90.0) / 6.0) ** 2)
         d = CosmosDataset(d.images, d.xy, d.is_ontarget, labels=d.labels, offset_samples=s,
                           offset_weights=(w / w.sum()).float())
+    if offsets == "peaked":  # weights spanning > 2^40: the packed histogram kernel keeps log-weights inside the exponent
+        s = torch.arange(70.0, 110.0)
+        w = torch.exp(-0.5 * ((s - 90.0) / 2.0) ** 2).double()
+        d = CosmosDataset(d.images, d.xy, d.is_ontarget, labels=d.labels, offset_samples=s, offset_weights=w / w.sum())
+    if offsets == "wide":  # offsets reaching above the dimmest pixels: some offsets are masked per pixel (ksmogn.py:226)
+        s = torch.arange(70.0, 330.0, 4.0)
+        w = torch.exp(-0.5 * ((s - 90.0) / 60.0) ** 2)
+        d = CosmosDataset(d.images, d.xy, d.is_ontarget, labels=d.labels, offset_samples=s,
+                          offset_weights=(w / w.sum()).float())
     if mask is not None:
         d.mask = mask
     return d

@@ -59,6 +59,8 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
   const bool bwd = a.g_background != nullptr;
   const bool one = a.O == 1 && a.pixstats != nullptr;
   const float g = a.gain[0], rg = 1.0f / g, ln_g = logf(g);
+  TqOffsetInfo hinfo;
+  tq_offset_info(a.offset_samples, a.offset_logits, a.O, &hinfo);
   for (int64_t i = 0; i < B; ++i) {
     const int c = (int)(i % a.C);
     const int64_t ab = i / a.C;
@@ -127,25 +129,15 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
         }
         for (int k = 0; k < K; ++k) SN[k] += spot[k];
       } else {
+        float mu[M], lp[M];
         for (int mi = 0; mi < M; ++mi) {
-          float mu = b, lp;
+          mu[mi] = b;
           for (int k = 0; k < K; ++k)
-            if ((mi >> k) & 1) mu += spot[k];
-          TqComboPix cp;
-          TqLse acc;
-          tq_combo_prepare(mu, rg, g, ln_g, &cp);
-          tq_lse_init(&acc);
-          for (int o = 0; o < a.O; ++o) {
-            const float v = D - a.offset_samples[o];
-            if (v > 0.0f) {
-              const float lv = logf(v);
-              tq_lse_push(&acc, cp, v, lv, a.offset_logits[o] - lv);
-            }
-          }
-          if (fast) tq_lse_finish<true>(acc, cp, rg, &lp, &da[mi], &gq[mi]);
-          else tq_lse_finish<false>(acc, cp, rg, &lp, &da[mi], &gq[mi]);
-          ll[mi] += lp;
+            if ((mi >> k) & 1) mu[mi] += spot[k];
         }
+        if (fast) tq_pix_multi_offset<M, true, true>(D, mu, a.offset_samples, a.offset_logits, a.O, hinfo, g, rg, ln_g, lp, da, gq);
+        else tq_pix_multi_offset<M, true, false>(D, mu, a.offset_samples, a.offset_logits, a.O, hinfo, g, rg, ln_g, lp, da, gq);
+        for (int mi = 0; mi < M; ++mi) ll[mi] += lp[mi];
       }
       if (bwd) {
         float q[K];

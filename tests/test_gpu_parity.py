@@ -167,6 +167,9 @@ IL_CASES = [  # contiguous batches through the lane-per-unit kernel on the inter
     ("K3_P9_npix_not_multiple_of_4", dict(N=2, F=3, P=9), 3),
     ("K2_two_channels", dict(N=3, F=5, C=2), 2),
     ("K2_offset_histogram", dict(N=2, F=3, offsets="hist"), 2),
+    ("K2_offsets_partly_masked", dict(N=2, F=3, offsets="wide"), 2),
+    ("K2_offsets_peaked_weights", dict(N=2, F=3, offsets="peaked"), 2),
+    ("K3_offset_histogram", dict(N=2, F=2, offsets="hist"), 3),
     ("K2_P20", dict(N=2, F=2, P=20), 2),
     ("K3_P20", dict(N=2, F=2, P=20), 3),           # the c5 shape: packed kernel, row-at-a-time bodies
     ("K3_P14", dict(N=2, F=3), 3),

@@ -19,6 +19,8 @@ CASES = [
     ("K2_fullbatch", dict(N=4, F=3), 2, None, None),
     ("K2_two_channels", dict(N=4, F=3, C=2), 2, [0, 3], [0, 2]),
     ("K2_offset_histogram", dict(N=2, F=3, offsets="hist"), 2, None, None),
+    ("K2_offsets_partly_masked", dict(N=2, F=3, offsets="wide"), 2, None, None),
+    ("K2_offsets_peaked_weights", dict(N=2, F=3, offsets="peaked"), 2, None, None),
     ("K2_P20", dict(N=2, F=2, P=20), 2, None, None),
     ("K2_masked_aoi", dict(N=4, F=3, mask=torch.tensor([True, False, True, True])), 2, None, None),
 ]
