@@ -92,6 +92,53 @@ typedef struct {
 
 int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * KSMOGN likelihood of the crosstalk model (Q = C = 2 dyes / channels).
+ * Replaces: the `alpha is not None` branch of tapqir/distributions/ksmogn.py:93-105, 146-165 as used by
+ * tapqir/models/crosstalk.py:262-281: one observation per AOI-frame with event shape (C, P, P),
+ *   image_c = b_c + sum_q alpha_qc sum_k m_qk h_qk N(x_qk + tx_c, y_qk + ty_c; w_qk),
+ * for every joint spot-presence combination (bit q*K + k of the combination index = m_qk).
+ * Units follow the cosmos layout: unit g*C + c of AOI-frame g carries background b_c and the spots of dye
+ * q = c.  Outputs: the joint log-likelihoods (`ll_joint`), and/or, with `m_logit`, the per-dye marginals
+ *   ll[mq][g*C + q] = sum_{m_-q} q(m_-q) ll_joint(m_q, m_-q)
+ * that the cosmos per-unit routine consumes, plus `ell_excess` (the part of the ELBO those marginals count
+ * more than once).  Backward as in tq_ksmogn_log_prob, with the extra output g_alpha.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* images;         /* (Nt, F, C, P, P) */
+  const float* xy;             /* (Nt, F, C, 2) */
+  const int32_t* ndx;          /* [nb] or NULL */
+  const int32_t* fdx;          /* [fb] or NULL */
+  const float* background;     /* [B]    B = nb*fb*C, unit g*C + c */
+  const float* height;         /* [K][B] unit g*C + q */
+  const float* width;
+  const float* x;
+  const float* y;
+  const float* gain;           /* [1] */
+  const float* alpha;          /* [Q*C] crosstalk fractions alpha[q][c] */
+  const float* offset_samples; /* [O] */
+  const float* offset_logits;  /* [O] */
+  const float* gout;           /* [2^(QK)][nb*fb] upstream weights of the joint combinations, or NULL */
+  const float* m_logit;        /* (K, Nt, F, Q) unconstrained m_probs: Dice weights and per-dye marginals */
+  const uint8_t* aoi_mask;     /* [Nt] or NULL */
+  float* ll_joint;             /* [2^(QK)][nb*fb] out or NULL */
+  float* ll;                   /* [2^K][B] out or NULL (needs m_logit) */
+  float* ell_excess;           /* [B] out or NULL */
+  float* g_background;         /* [B] out or NULL (forward only) */
+  float* g_height;             /* [K][B] */
+  float* g_width;
+  float* g_x;
+  float* g_y;
+  float* g_gain;               /* [B] per-unit partial (whole AOI-frame in unit c = 0) */
+  float* g_alpha;              /* [Q][B]: row q, unit g*C + c = d/d alpha[q][c] */
+  int64_t m_kstride;           /* = Nt*F*Q */
+  int32_t nb, fb, C, F;
+  int32_t P, K, O;
+  float scale;
+} tq_xtalk_args;
+
+int tq_ksmogn_crosstalk_log_prob(const tq_xtalk_args* a, void* stream);
+
 /* Tile-interleaved copy of the image tensor for the contiguous-batch kernel: units in blocks of 64,
  * pixels in groups of 4, so that a wave64 reads one contiguous 1 KiB row per load:
  *   out[((u / 64) * npix4 + q) * 64 + (u % 64)] = float4{ pixels 4q..4q+3 of unit u },  npix4 = ceil(P*P/4)
@@ -143,9 +190,10 @@ typedef struct {
   float* lat;                  /* [1+4K][B]        latent draws: b, h[K], w[K], x[K], y[K] */
   float* site;                 /* [6][(1+4K)*B]    per-site guide terms (log q, its derivatives, implicit
                                                    reparameterisation gradients), same site order as lat */
-  float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K] */
+  float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K]
+                                                   (crosstalk: 1+Q more rows: ell_excess, g_alpha[Q]) */
   float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */
-  float* blk_part;             /* [nblk][3+3Q]     per-workgroup partial sums */
+  float* blk_part;             /* [nblk][3+3Q]     per-workgroup partial sums (crosstalk: 3+3Q+Q*Q) */
   double* gsum;                /* [TQ_GSUM_LEN]    cross-unit sums: d/d gain, d/d cs, ELBO, (d/d rho, a, c)[Q] in the
                                                    first 3+3Q entries (the part a data-parallel host
                                                    all-reduces); the tail is scratch of the library */
@@ -178,6 +226,10 @@ typedef struct {
                                   HIP stream of the library, concurrently with the next step's local guide sampling.
                                   Results (elbo_out, global parameters) are then complete on `stream` only after
                                   tq_cosmos_join(stream) or a device synchronisation */
+  int32_t crosstalk;           /* 1: the crosstalk model (tapqir/models/crosstalk.py; Q = C = 2, K <= 2): one data site per
+                                  AOI-frame whose channel c sees every dye's spots scaled by alpha[q][c]; the global block
+                                  of the parameter buffer grows by alpha_mean[Q][2], alpha_size[Q] (4+8Q entries), gsum
+                                  by d/d alpha[q][c] (3+3Q+Q*Q entries) */
   /* RNG */
   uint64_t seed;
   uint32_t step;
@@ -187,6 +239,7 @@ int64_t tq_globals_size(void);
 int64_t tq_gbase_size(void);
 int64_t tq_cosmos_nblk(int64_t B);              /* rows of blk_part */
 int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K);
+int64_t tq_crosstalk_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K);  /* + alpha_mean, alpha_size */
 
 /* guide draws: globals (gain, pi, lamda, proximity) + derived tables; then, one lane per
  * (unit, site), b, h, w, x, y (cosmos.py:342-368, 408-462; torch Gamma/Beta rsample + pyro

@@ -77,3 +77,28 @@ def ksmogn_rsample(height, width, x, y, target_locs, background, gain, offset_sa
         val = torch._standard_gamma(conc, generator=generator) * gain
     val = val.clamp(min=torch.finfo(val.dtype).tiny)
     return val + offset_samples[odx]
+
+
+def ksmogn_crosstalk_image(height, width, x, y, target_locs, background, P, m, alpha):
+    """Crosstalk branch of KSMOGN (ksmogn.py:93-105, 146-165).
+    height/width/x/y/m: (..., Q, K); target_locs (..., C, 2); background (..., C); alpha (Q, C)
+    -> (..., C, P, P):  image_c = b_c + sum_q alpha_qc sum_k m_qk h_qk N(x_qk + tx_c, y_qk + ty_c; w_qk)."""
+    h = height.unsqueeze(-2) * alpha[..., None]  # (..., Q, C, K)
+    g = gaussian_spots(h, width.unsqueeze(-2), x.unsqueeze(-2), y.unsqueeze(-2),
+                       target_locs.unsqueeze(-3).unsqueeze(-2), P,
+                       None if m is None else m.unsqueeze(-2))  # (..., Q, C, K, P, P)
+    return background[..., None, None] + g.sum(-5).sum(-3)
+
+
+def ksmogn_crosstalk_log_prob(value, height, width, x, y, target_locs, background, gain,
+                              offset_samples, offset_logits, P, m, alpha):
+    """Dense-torch branch (ksmogn.py:222-238) with event shape (C, P, P).  value (..., C, P, P)."""
+    image = ksmogn_crosstalk_image(height, width, x, y, target_locs, background, P, m, alpha)
+    rate = 1 / gain
+    conc = (image / gain).unsqueeze(-1)
+    v = value.unsqueeze(-1)
+    mask = v > offset_samples
+    nv = torch.where(mask, v - offset_samples, torch.ones((), dtype=v.dtype))
+    obs = conc * torch.log(rate) + (conc - 1) * torch.log(nv) - rate * nv - torch.lgamma(conc)
+    res = torch.logsumexp(obs + offset_logits + torch.log(mask.to(v.dtype)), -1)
+    return res.sum((-1, -2, -3))

@@ -60,8 +60,26 @@ class CosmosArgs(C.Structure):
         ("gain_std", C.c_float), ("lamda_rate", C.c_float), ("proximity_rate", C.c_float),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("bias_correction1", C.c_float), ("bias_correction2", C.c_float),
-        ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32), ("overlap_globals", C.c_int32),
+        ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32), ("overlap_globals", C.c_int32), ("crosstalk", C.c_int32),
         ("seed", C.c_uint64), ("step", C.c_uint32),
+    ]
+
+
+class XtalkArgs(C.Structure):
+    """``tq_xtalk_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("images", C.c_void_p), ("xy", C.c_void_p), ("ndx", C.c_void_p), ("fdx", C.c_void_p),
+        ("background", C.c_void_p), ("height", C.c_void_p), ("width", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+        ("gain", C.c_void_p), ("alpha", C.c_void_p), ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
+        ("gout", C.c_void_p), ("m_logit", C.c_void_p), ("aoi_mask", C.c_void_p),
+        ("ll_joint", C.c_void_p), ("ll", C.c_void_p), ("ell_excess", C.c_void_p),
+        ("g_background", C.c_void_p), ("g_height", C.c_void_p), ("g_width", C.c_void_p), ("g_x", C.c_void_p),
+        ("g_y", C.c_void_p), ("g_gain", C.c_void_p), ("g_alpha", C.c_void_p),
+        ("m_kstride", C.c_int64),
+        ("nb", C.c_int32), ("fb", C.c_int32), ("C", C.c_int32), ("F", C.c_int32),
+        ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
+        ("scale", C.c_float),
     ]
 
 
@@ -78,7 +96,8 @@ class ProbsArgs(C.Structure):
 
 # every symbol include/tapqir_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "tq_version", "tq_last_error", "tq_ksmogn_log_prob", "tq_interleaved_floats", "tq_images_interleave", "tq_image_stats",
+    "tq_version", "tq_last_error", "tq_ksmogn_log_prob", "tq_ksmogn_crosstalk_log_prob", "tq_crosstalk_param_count",
+    "tq_interleaved_floats", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_join", "tq_cosmos_probs",
@@ -109,6 +128,10 @@ def load():
     lib.tq_cosmos_nblk.argtypes = [C.c_int64]
     lib.tq_cosmos_param_count.restype = C.c_int64
     lib.tq_cosmos_param_count.argtypes = [C.c_int32] * 4
+    lib.tq_crosstalk_param_count.restype = C.c_int64
+    lib.tq_crosstalk_param_count.argtypes = [C.c_int32] * 4
+    lib.tq_ksmogn_crosstalk_log_prob.argtypes = [C.POINTER(XtalkArgs), C.c_void_p]
+    lib.tq_ksmogn_crosstalk_log_prob.restype = C.c_int
     lib.tq_interleaved_floats.restype = C.c_int64
     lib.tq_interleaved_floats.argtypes = [C.c_int64, C.c_int32]
     lib.tq_images_interleave.restype = C.c_int

@@ -26,10 +26,14 @@ TQ_HD int64_t tq_num_units(const tq_cosmos_args& a) { return (int64_t)a.Nt * a.F
 TQ_HD int64_t tq_batch_units(const tq_cosmos_args& a) { return (int64_t)a.nb * a.fb * a.C; }
 TQ_HD int64_t tq_aoi_base(const tq_cosmos_args& a) { return (int64_t)TQ_NLOCAL(a.K) * tq_num_units(a); }
 TQ_HD int64_t tq_global_base(const tq_cosmos_args& a) { return tq_aoi_base(a) + 2 * (int64_t)a.Nt * a.C; }
+TQ_HD int tq_num_gsum(const tq_cosmos_args& a) { return TQ_NGSUM_X(a.C, a.crosstalk); }
+TQ_HD int tq_num_gsites(const tq_cosmos_args& a) { return TQ_NGSITES_X(a.C, a.crosstalk); }
+TQ_HD int64_t tq_num_params(const tq_cosmos_args& a) { return tq_global_base(a) + TQ_NGLOBAL_X(a.C, a.crosstalk); }
 
 TQ_HD TqGlobalConsts tq_global_consts(const tq_cosmos_args& a) {
   TqGlobalConsts c;
   c.K = a.K; c.P = a.P; c.Q = a.C;
+  c.xt = a.crosstalk;
   c.eps = a.eps;
   c.gain_std = a.gain_std; c.lamda_rate = a.lamda_rate; c.proximity_rate = a.proximity_rate;
   return c;
@@ -174,7 +178,7 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
   a.aoi_part[i] = masked ? 0.0f : out.g_bml;
   a.aoi_part[B + i] = masked ? 0.0f : out.g_bsl;
 
-  const int nq = 3 + 3 * a.C;
+  const int nq = tq_num_gsum(a);
   for (int j = 0; j < nq; ++j) part[j] = 0.0f;
   if (!masked) {
     part[TQ_GS_GAIN] = g_gain;
@@ -183,6 +187,13 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
     part[TQ_GS_Q0 + 3 * ix.c + 0] = out.d_rho;
     part[TQ_GS_Q0 + 3 * ix.c + 1] = out.d_a;
     part[TQ_GS_Q0 + 3 * ix.c + 2] = out.d_c;
+    if (a.crosstalk) {
+      // rows after the cosmos block of pix: [ell_excess][g_alpha[q]] (tq_xtalk.h).  in.ll held the per-dye
+      // MARGINAL likelihoods, so every dye's Dice sum contains E[ll]: remove the copies beyond the first
+      const int64_t x0 = (int64_t)(M + 2 + 4 * K) * B;
+      part[TQ_GS_ELBO] -= in.wu * a.pix[x0 + i];
+      for (int q = 0; q < a.C; ++q) part[TQ_GS_ALPHA0(a.C) + q * a.C + ix.c] = a.pix[x0 + (int64_t)(1 + q) * B + i];
+    }
   }
 }
 
@@ -229,6 +240,7 @@ TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
 TQ_HD void tq_body_probs_globals(const tq_probs_args& a, int s, int particle) {
   TqGlobalConsts C;
   C.K = a.K; C.P = a.P; C.Q = a.C; C.eps = a.eps;
+  C.xt = 0;  // alpha does not enter the z / theta posterior
   C.gain_std = C.lamda_rate = C.proximity_rate = 1.0;  // priors are not used for draws
   const int64_t U = (int64_t)a.Nt * a.F * a.C;
   const float* ug = a.params + (int64_t)TQ_NLOCAL(a.K) * U + 2 * (int64_t)a.Nt * a.C;

@@ -14,7 +14,7 @@
 void tq_set_error(const char* msg);
 
 #define TQ_UNIT_BLOCK 256
-#define TQ_MAX_NGSUM (3 + 3 * TQ_MAXQ)
+#define TQ_MAX_NGSUM (3 + 3 * TQ_MAXQ)  // >= 3 + 3*2 + 2*2 of the crosstalk model
 
 __device__ __forceinline__ float tq_wave_sum(float v) {
 #pragma unroll
@@ -38,7 +38,7 @@ template <int K>
 __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_kernel(const tq_cosmos_args a, const int64_t B) {
   __shared__ float s_part[TQ_UNIT_BLOCK / 64][TQ_MAX_NGSUM];
   const int64_t i = (int64_t)blockIdx.x * TQ_UNIT_BLOCK + threadIdx.x;
-  const int nq = 3 + 3 * a.C;
+  const int nq = tq_num_gsum(a);
   float part[TQ_MAX_NGSUM];
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void tq_aoi_kernel(const tq_cosmos_args a, con
 // ---- finish the cross-unit sums in fp64 (single workgroup) -----------------------------------------------
 __global__ __launch_bounds__(256) void tq_reduce_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
   __shared__ double s_red[256];
-  const int nq = 3 + 3 * a.C;
+  const int nq = tq_num_gsum(a);
   for (int j = 0; j < nq; ++j) {
     double s = 0.0;
     for (int64_t r = threadIdx.x; r < nblk; r += 256) s += (double)a.blk_part[r * nq + j];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void tq_globals_grad_kernel(const tq_cosmos_arg
 __global__ __launch_bounds__(64) void tq_elbo_finish_kernel(const tq_cosmos_args a, const double* site_elbo) {
   if (threadIdx.x == 0) {
     double eg = 0.0;
-    const int ns = TQ_NGSITES(a.C);
+    const int ns = tq_num_gsites(a);
     for (int j = 0; j < ns; ++j) eg += site_elbo[j];
     a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
   }
@@ -137,7 +137,7 @@ __device__ __forceinline__ double tq_wave_sum_d(double v) {
 __global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
   __shared__ double s_w[4][TQ_MAX_NGSUM];
   __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
-  const int nq = 3 + 3 * a.C;
+  const int nq = tq_num_gsum(a);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // every thread walks the rows once, carrying all columns (nq <= 15); then shuffle + 4-way LDS sum
   double acc[TQ_MAX_NGSUM];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_
   if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
   __threadfence_block();
   __syncthreads();
-  const int ns = TQ_NGSITES(a.C);
+  const int ns = tq_num_gsites(a);
   if (lane == 0)
     for (int s = wave; s < ns; s += 4) s_e[s] = tq_body_globals_grad(a, s);
   __syncthreads();
@@ -194,6 +194,10 @@ static int check_args(const tq_cosmos_args* a, const char* who) {
     tq_set_error("tq_cosmos_*: unsupported K/P/C or inconsistent batch geometry");
     return TQ_ERR_ARG;
   }
+  if (a->crosstalk && (a->C != 2 || a->K > 2)) {
+    tq_set_error("tq_cosmos_*: the crosstalk model is implemented for Q = C = 2 and K <= 2");
+    return TQ_ERR_ARG;
+  }
   (void)who;
   return TQ_OK;
 }
@@ -204,10 +208,13 @@ extern "C" int64_t tq_cosmos_nblk(int64_t B) { return (B + TQ_UNIT_BLOCK - 1) / 
 extern "C" int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K) {
   return (int64_t)TQ_NLOCAL(K) * Nt * F * C + 2 * (int64_t)Nt * C + TQ_NGLOBAL(C);
 }
+extern "C" int64_t tq_crosstalk_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K) {
+  return (int64_t)TQ_NLOCAL(K) * Nt * F * C + 2 * (int64_t)Nt * C + TQ_NGLOBAL_X(C, 1);
+}
 
 extern "C" int tq_cosmos_sample_globals(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "sample_globals")) return rc;
-  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(TQ_NGSITES(a->C)), dim3(64), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(tq_sample_globals_kernel, dim3(tq_num_gsites(*a)), dim3(64), 0, (hipStream_t)stream, *a);
   return check_launch("tq_sample_globals_kernel");
 }
 
@@ -260,7 +267,27 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
   k.g_y = a->pix + (int64_t)(M + 2 + 3 * K) * B;
   k.nb = a->nb; k.fb = a->fb; k.C = a->C; k.F = a->F; k.P = a->P; k.K = K; k.O = a->O;
   k.scale = a->scale;
-  if (int rc = tq_ksmogn_log_prob(&k, stream)) return rc;
+  if (a->crosstalk) {
+    // one data site per AOI-frame, all dyes in every channel: per-dye marginal likelihoods go where the cosmos
+    // per-unit routine expects ll, two more row groups follow the cosmos block of pix
+    tq_xtalk_args x = {};
+    x.images = a->images; x.xy = a->xy; x.ndx = a->ndx; x.fdx = a->fdx;
+    x.background = k.background; x.height = k.height; x.width = k.width; x.x = k.x; x.y = k.y;
+    x.gain = k.gain;
+    x.alpha = &((const TqGlobals*)a->globals)->alpha[0][0];
+    x.offset_samples = a->offset_samples; x.offset_logits = a->offset_logits;
+    x.gout = nullptr; x.m_logit = a->params; x.m_kstride = U; x.aoi_mask = a->aoi_mask;
+    x.ll_joint = nullptr; x.ll = a->pix;
+    x.ell_excess = a->pix + (int64_t)(M + 2 + 4 * K) * B;
+    x.g_alpha = a->pix + (int64_t)(M + 3 + 4 * K) * B;
+    x.g_background = k.g_background; x.g_gain = k.g_gain;
+    x.g_height = k.g_height; x.g_width = k.g_width; x.g_x = k.g_x; x.g_y = k.g_y;
+    x.nb = a->nb; x.fb = a->fb; x.C = a->C; x.F = a->F; x.P = a->P; x.K = K; x.O = a->O;
+    x.scale = a->scale;
+    if (int rc = tq_ksmogn_crosstalk_log_prob(&x, stream)) return rc;
+  } else if (int rc = tq_ksmogn_log_prob(&k, stream)) {
+    return rc;
+  }
   // 2. per-unit sites
   const int64_t nblk = tq_cosmos_nblk(B);
   const dim3 grid((unsigned)nblk), block(TQ_UNIT_BLOCK);
@@ -291,8 +318,8 @@ extern "C" int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream) {
   }
   // per-site ELBO parts go through the tail of the gsum buffer (gsum has 3+3Q used entries; the
   // caller allocates TQ_GSUM_LEN doubles)
-  double* site_elbo = a->gsum + (3 + 3 * a->C);
-  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(TQ_NGSITES(a->C)), dim3(64), 0, (hipStream_t)stream, *a, site_elbo);
+  double* site_elbo = a->gsum + tq_num_gsum(*a);
+  hipLaunchKernelGGL(tq_globals_grad_kernel, dim3(tq_num_gsites(*a)), dim3(64), 0, (hipStream_t)stream, *a, site_elbo);
   if (int rc = check_launch("tq_globals_grad_kernel")) return rc;
   hipLaunchKernelGGL(tq_elbo_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a, (const double*)site_elbo);
   return check_launch("tq_elbo_finish_kernel");
@@ -304,7 +331,7 @@ extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {
     tq_set_error("tq_cosmos_adam: NULL required pointer");
     return TQ_ERR_ARG;
   }
-  const int64_t total = tq_cosmos_param_count(a->Nt, a->F, a->C, a->K);
+  const int64_t total = tq_num_params(*a);
   // with fuse_adam the local block was already updated by the per-unit kernel
   const int64_t first = a->fuse_adam ? tq_aoi_base(*a) : 0;
   int64_t nblk = (total - first + 255) / 256;

@@ -14,9 +14,15 @@
 #include "tq_math.h"
 #include "tq_site.h"
 
+//
+// The crosstalk model (tapqir/models/crosstalk.py:80-87, 279-284, 429-438; Q = C = 2) appends
+//   [4+5Q .. 4+7Q)  alpha_mean[q][0..1]   [4+7Q .. 4+8Q)  alpha_size[q]
 #define TQ_NGLOBAL(Q) (4 + 5 * (Q))
-// per-rank partial sums that cross GPUs in ONE all-reduce: [gain, cs, elbo, (rho, a, c) x Q]
+#define TQ_NGLOBAL_X(Q, xt) (4 + 5 * (Q) + ((xt) ? 3 * (Q) : 0))
+// per-rank partial sums that cross GPUs in ONE all-reduce: [gain, cs, elbo, (rho, a, c) x Q] (+ d/d alpha[q][c])
 #define TQ_NGSUM(Q) (3 + 3 * (Q))
+#define TQ_NGSUM_X(Q, xt) (3 + 3 * (Q) + ((xt) ? (Q) * (Q) : 0))
+#define TQ_GS_ALPHA0(Q) (3 + 3 * (Q))
 enum { TQ_GS_GAIN = 0, TQ_GS_CS = 1, TQ_GS_ELBO = 2, TQ_GS_Q0 = 3 };
 
 struct TqGlobalBase {  // base draws behind the global latents
@@ -24,10 +30,12 @@ struct TqGlobalBase {  // base draws behind the global latents
   double prox_t;
   double lamda_g[TQ_MAXQ];
   double pi_x[TQ_MAXQ][2];
+  double alpha_x[2][2];  // crosstalk model only
 };
 
 struct TqGlobalConsts {
   int K, P, Q;
+  int xt;  // crosstalk model: Q more sites (alpha_q)
   double eps;
   double gain_std, lamda_rate, proximity_rate;
 };
@@ -66,6 +74,7 @@ struct TqGlobalSite {
 // has its own Philox stream, draws its own base variates and fills its own fields of TqGlobals, so
 // the device runs one site per wave (tq_cosmos.hip) and the host loops over s.
 #define TQ_NGSITES(Q) (2 + 2 * (Q))
+#define TQ_NGSITES_X(Q, xt) (2 + 2 * (Q) + ((xt) ? (Q) : 0))   // crosstalk: 2+2Q+q = alpha_q
 
 TQ_HD void tq_globals_constrain_site(const float* u, const TqGlobalConsts& C, int s, TqGlobalSite* p) {
   const int Q = C.Q;
@@ -84,13 +93,17 @@ TQ_HD void tq_globals_constrain_site(const float* u, const TqGlobalConsts& C, in
     p->loc = exp((double)u[4 + q]);
     p->beta = exp((double)u[4 + Q + q]);
   } else {
-    const int q = s - 2 - Q;
-    const double u0 = u[4 + 2 * Q + 2 * q], u1 = u[4 + 2 * Q + 2 * q + 1];
+    // pi_q, or alpha_q of the crosstalk model: softmax mean of 2 components and a positive size
+    const bool is_alpha = s >= 2 + 2 * Q;
+    const int q = is_alpha ? s - 2 - 2 * Q : s - 2 - Q;
+    const int im = is_alpha ? 4 + 5 * Q + 2 * q : 4 + 2 * Q + 2 * q;
+    const int is = is_alpha ? 4 + 7 * Q + q : 4 + 4 * Q + q;
+    const double u0 = u[im], u1 = u[im + 1];
     const double mx = u0 > u1 ? u0 : u1;
     const double e0 = exp(u0 - mx), e1 = exp(u1 - mx);
     p->m0 = e0 / (e0 + e1);
     p->m1 = e1 / (e0 + e1);
-    p->size = exp((double)u[4 + 4 * Q + q]);
+    p->size = exp((double)u[is]);
   }
 }
 
@@ -136,14 +149,21 @@ TQ_HD void tq_globals_sample_site(int s, const TqGlobalSite& p, const TqGlobalCo
     G->a[q] = (float)a;
     G->c[q] = (float)c;
   } else {
-    const int q = s - 2 - Q;
+    const bool is_alpha = s >= 2 + 2 * Q;
+    const int q = is_alpha ? s - 2 - 2 * Q : s - 2 - Q;
+    double* x = is_alpha ? b->alpha_x[q] : b->pi_x[q];
     if (draw) {
       const double g0 = tq_sample_std_gamma(&ph, (float)(p.m0 * p.size));
       const double g1 = tq_sample_std_gamma(&ph, (float)(p.m1 * p.size));
-      b->pi_x[q][0] = g0 / (g0 + g1);
-      b->pi_x[q][1] = g1 / (g0 + g1);
+      x[0] = g0 / (g0 + g1);
+      x[1] = g1 / (g0 + g1);
     }
-    G->rho[q] = (float)b->pi_x[q][1];
+    if (is_alpha) {
+      G->alpha[q][0] = (float)x[0];
+      G->alpha[q][1] = (float)x[1];
+    } else {
+      G->rho[q] = (float)x[1];
+    }
   }
 }
 
@@ -209,7 +229,8 @@ TQ_HD double tq_globals_grad_site(int s, const TqGlobalSite& p, const TqGlobalBa
     return lp - lq;
   }
   // ---- Beta / Dirichlet sites: proximity (AffineBeta on (0, Hs)) and pi_q (2-component Dirichlet) ----
-  double x0, c0, c1, go0, go1, lp, sc;  // x0 = first component; (c0, c1) concentrations of (x0, 1-x0)
+  double x0, x1, c0, c1, go0, go1, lp, sc;  // x0 = first component; (c0, c1) concentrations of (x0, x1)
+  const bool is_alpha = s >= 2 + 2 * Q;
   if (s == 1) {
     const double sg = G.proximity, rate = C.proximity_rate;
     lp = log(rate) - rate * sg;
@@ -222,9 +243,23 @@ TQ_HD double tq_globals_grad_site(int s, const TqGlobalSite& p, const TqGlobalBa
     go0 = clamped ? 0.0 : (gsum[TQ_GS_CS] * dcs_dsigma - rate) * Hs;  // pathwise part only
     go1 = 0.0;
     sc = Hs;
+    x1 = 1.0 - x0;
+  } else if (is_alpha) {
+    // alpha_q: prior Dirichlet(1 + 9 [q == c]) (crosstalk.py:82-87); likelihood derivative from the cross-unit sums
+    const int q = s - 2 - 2 * Q;
+    x0 = b.alpha_x[q][0];
+    x1 = b.alpha_x[q][1];
+    c0 = p.m0 * p.size;
+    c1 = p.m1 * p.size;
+    const double a0 = q == 0 ? 10.0 : 1.0, a1 = q == 1 ? 10.0 : 1.0;
+    lp = 2.30258509299404568402 + (a0 - 1.0) * log(x0) + (a1 - 1.0) * log(x1);  // lgamma(11) - lgamma(10) - lgamma(1) = ln 10
+    go0 = gsum[TQ_GS_ALPHA0(Q) + 2 * q + 0] + (a0 - 1.0) / x0;
+    go1 = gsum[TQ_GS_ALPHA0(Q) + 2 * q + 1] + (a1 - 1.0) / x1;
+    sc = 1.0;
   } else {
     const int q = s - 2 - Q;
     x0 = b.pi_x[q][0];
+    x1 = b.pi_x[q][1];
     c0 = p.m0 * p.size;
     c1 = p.m1 * p.size;
     lp = -2.0 * 0.57236494292470008707 - 0.5 * log(x0) - 0.5 * log(1.0 - x0);  // Dirichlet(1/2,1/2): lgamma(1/2) = ln sqrt(pi)
@@ -232,7 +267,6 @@ TQ_HD double tq_globals_grad_site(int s, const TqGlobalSite& p, const TqGlobalBa
     go1 = gsum[TQ_GS_Q0 + 3 * q + 0] - 0.5 / b.pi_x[q][1];
     sc = 1.0;
   }
-  const double x1 = (s == 1) ? 1.0 - x0 : b.pi_x[s - 2 - Q][1];
   const double tot = c0 + c1;
   double lg0, dg0, lg1, dg1, lgt, dgt;
   tq_lgamma_digamma_d(c0, &lg0, &dg0);
@@ -255,13 +289,15 @@ TQ_HD double tq_globals_grad_site(int s, const TqGlobalSite& p, const TqGlobalBa
     g[2] = (float)(d_loc * (Hs - C.eps) * p.sg * (1 - p.sg));
     g[3] = (float)(d_size * p.ex);
   } else {
-    const int q = s - 2 - Q;
+    const int q = is_alpha ? s - 2 - 2 * Q : s - 2 - Q;
+    const int im = is_alpha ? 4 + 5 * Q + 2 * q : 4 + 2 * Q + 2 * q;
+    const int is = is_alpha ? 4 + 7 * Q + q : 4 + 4 * Q + q;
     const double d_ps = g_c0 * p.m0 + g_c1 * p.m1;
     const double d_m0 = g_c0 * p.size, d_m1 = g_c1 * p.size;
     const double mdot = p.m0 * d_m0 + p.m1 * d_m1;
-    g[4 + 2 * Q + 2 * q + 0] = (float)(p.m0 * (d_m0 - mdot));
-    g[4 + 2 * Q + 2 * q + 1] = (float)(p.m1 * (d_m1 - mdot));
-    g[4 + 4 * Q + q] = (float)(d_ps * p.size);
+    g[im + 0] = (float)(p.m0 * (d_m0 - mdot));
+    g[im + 1] = (float)(p.m1 * (d_m1 - mdot));
+    g[is] = (float)(d_ps * p.size);
   }
   return lp - lq;
 }

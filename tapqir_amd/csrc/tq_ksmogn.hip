@@ -24,24 +24,13 @@
 #include <type_traits>
 
 #include "../../include/tapqir_hip.h"
+#include "tq_dpp.h"
 #include "tq_pixel.h"
 
 #define TQ_LANES_PER_UNIT 16
 #define TQ_UNITS_PER_BLOCK 16
 #define TQ_BLOCK (TQ_LANES_PER_UNIT * TQ_UNITS_PER_BLOCK)
 
-template <int CTRL>
-__device__ __forceinline__ float tq_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float tq_group_sum16(float v) {
-  // sum over the 16 lanes of a unit = one DPP row: data-parallel-primitive adds, no LDS crossbar.
-  v += tq_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += tq_dpp<0x4E>(v);   // quad_perm [2,3,0,1]   -> quad sums
-  v += tq_dpp<0x141>(v);  // row_half_mirror       -> sums of 8
-  v += tq_dpp<0x140>(v);  // row_mirror            -> sum of 16, in every lane
-  return v;
-}
 __device__ __forceinline__ float tq_fast_sigmoid(float u) { return TQ_FRCP(1.0f + TQ_FEXP(-u)); }
 
 // LDS of the 16-lane kernel: [16 units][tile stride] staged pixels, then [16 units][2K][P] factors.

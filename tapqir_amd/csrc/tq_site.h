@@ -47,6 +47,7 @@ struct TqGlobals {
   float rho[TQ_MAXQ];       // pi_q[1]
   float a[TQ_MAXQ];         // probs_m[q, theta=0, k]
   float c[TQ_MAXQ];         // probs_m[q, theta=k'+1, k != k']   (K >= 2)
+  float alpha[2][2];        // crosstalk model only: alpha[q][c], fraction of dye q's signal in channel c
 };
 
 struct TqSiteConsts {

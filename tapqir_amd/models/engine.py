@@ -39,7 +39,7 @@ def merge_offsets(samples, weights):
 
 class CosmosEngine:
     def __init__(self, data, K=2, priors=None, device="cuda", eps=None, seed=0, lib=None,
-                 n_offset=0, Nt_global=None):
+                 n_offset=0, Nt_global=None, crosstalk=False):
         self.device = torch.device(device)
         self._hostcheck = lib is not None
         if lib is None:
@@ -49,6 +49,11 @@ class CosmosEngine:
                     f"(device={device!r} requested); there is no CPU path")
             lib = _lib.load()
         self.lib = lib
+        self.crosstalk = bool(crosstalk)
+        if self.crosstalk and (int(data.images.shape[2]) != 2 or int(K) > 2):
+            raise ValueError("the crosstalk model is implemented for Q = C = 2 dyes/channels and K <= 2 "
+                             "(2^(K Q) joint spot-presence combinations; tapqir/models/crosstalk.py is experimental "
+                             "upstream and indexes dyes and channels alike)")
         self.K = int(K)
         self.priors = dict(DEFAULT_PRIORS if priors is None else priors)
         self.eps = float(torch.finfo(torch.float32).eps if eps is None else eps)
@@ -66,7 +71,7 @@ class CosmosEngine:
         # tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the
         # library so that any C caller gets the same layout
         self.images_il = None
-        if not self._hostcheck:
+        if not self._hostcheck and not self.crosstalk:
             U = self.Nt * self.F * self.C
             n_il = int(lib.tq_interleaved_floats(U, self.P))
             self.images_il = torch.empty(n_il, dtype=f32, device=dev)
@@ -78,7 +83,7 @@ class CosmosEngine:
         self.O = int(off_s.numel())
         # per-unit data statistics of the single-offset formulation (sum v, sum ln v, #masked pixels)
         self.pixstats = None
-        if self.O == 1:
+        if self.O == 1 and not self.crosstalk:
             U = self.Nt * self.F * self.C
             self.pixstats = torch.empty(3 * U, dtype=f32, device=dev)
             if self._hostcheck:
@@ -88,7 +93,7 @@ class CosmosEngine:
                 _lib.check(lib.tq_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples),
                                               _lib.ptr(self.pixstats), U, self.P,
                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tq_image_stats")
-        self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps)
+        self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps, crosstalk=self.crosstalk)
         n = self.layout.total
         self.params = torch.zeros(n, dtype=f32, device=dev)
         self.grad = torch.zeros(n, dtype=f32, device=dev)
@@ -99,7 +104,8 @@ class CosmosEngine:
         self.globals = torch.zeros(gsz // 4, dtype=f32, device=dev)
         self.gbase = torch.zeros(bsz // 8, dtype=torch.float64, device=dev)
         self._gsum_buf = torch.zeros(32, dtype=torch.float64, device=dev)  # TQ_GSUM_LEN
-        self.gsum = self._gsum_buf[: 3 + 3 * self.C]  # the part that crosses ranks
+        self.n_gsum = 3 + 3 * self.C + (self.C * self.C if self.crosstalk else 0)
+        self.gsum = self._gsum_buf[: self.n_gsum]  # the part that crosses ranks
         self.elbo_out = torch.zeros(1, dtype=torch.float64, device=dev)
         self._ws_key = None
         self.adam_step = 0
@@ -122,10 +128,10 @@ class CosmosEngine:
         dev, f32 = self.device, torch.float32
         self.lat = torch.zeros((1 + 4 * K) * B, dtype=f32, device=dev)
         self.site = torch.zeros(6 * (1 + 4 * K) * B, dtype=f32, device=dev)
-        self.pix = torch.zeros((M + 2 + 4 * K) * B, dtype=f32, device=dev)
+        self.pix = torch.zeros((M + 2 + 4 * K + (1 + self.C if self.crosstalk else 0)) * B, dtype=f32, device=dev)
         self.aoi_part = torch.zeros(3 * B, dtype=f32, device=dev)
         nblk = (B + 255) // 256
-        self.blk_part = torch.zeros(nblk * (3 + 3 * self.C), dtype=f32, device=dev)
+        self.blk_part = torch.zeros(nblk * self.n_gsum, dtype=f32, device=dev)
         self._ws_key = key
 
     def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None):
@@ -166,6 +172,7 @@ class CosmosEngine:
         a.bias_correction2 = 1.0 - self.betas[1] ** t
         a.zero_grad = int(nb < self.Nt or fb < self.F)
         a.fuse_adam = 0  # set by step() for full-batch steps
+        a.crosstalk = int(self.crosstalk)
         a.seed = self.seed
         a.step = self.adam_step if step is None else int(step)
         return a

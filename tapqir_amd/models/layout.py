@@ -12,7 +12,8 @@ of that buffer with exactly the reference's shape:
     [ per-AOI 2 x Nt*C   ]  background_mean_loc, background_std_loc : (Nt, 1, C)
     [ global  4 + 5Q     ]  gain_loc, gain_beta, proximity_loc, proximity_size : ()
                             lamda_loc, lamda_beta : (Q,)   pi_mean : (Q, 2)   pi_size : (Q, 1)
-(the C ABI states the same layout in include/tapqir_hip.h).
+(the C ABI states the same layout in include/tapqir_hip.h).  The crosstalk model
+(tapqir/models/crosstalk.py:429-438) appends  alpha_mean : (Q, C)  and  alpha_size : (Q, 1)  to the global block.
 """
 
 import math
@@ -24,12 +25,13 @@ LOCAL_K_NAMES = ["m_probs", "h_loc", "h_beta", "w_mean", "w_size", "x_mean", "y_
 
 
 class ParamLayout:
-    def __init__(self, Nt, F, C, K, P, eps):
+    def __init__(self, Nt, F, C, K, P, eps, crosstalk=False):
         self.Nt, self.F, self.C, self.K, self.P, self.Q = Nt, F, C, K, P, C
+        self.crosstalk = bool(crosstalk)
         self.U = Nt * F * C
         self.n_local = (8 * K + 2) * self.U
         self.n_aoi = 2 * Nt * C
-        self.n_global = 4 + 5 * C
+        self.n_global = 4 + 5 * C + (3 * C if crosstalk else 0)
         self.total = self.n_local + self.n_aoi + self.n_global
         self.eps = eps
 
@@ -53,6 +55,9 @@ class ParamLayout:
         s["lamda_beta"] = (g + 4 + Q, (Q,))
         s["pi_mean"] = (g + 4 + 2 * Q, (Q, 2))
         s["pi_size"] = (g + 4 + 4 * Q, (Q, 1))
+        if self.crosstalk:
+            s["alpha_mean"] = (g + 4 + 5 * Q, (Q, C))
+            s["alpha_size"] = (g + 4 + 7 * Q, (Q, 1))
         return s
 
     def views(self, flat):
@@ -68,7 +73,7 @@ class ParamLayout:
         P, e = self.P, self.eps
         H = (P + 1) / 2
         c = constraints
-        return {
+        cons = {
             "pi_mean": c.simplex, "pi_size": c.positive, "m_probs": c.unit_interval,
             "proximity_loc": c.interval(0.0, (P + 1) / math.sqrt(12) - e),
             "proximity_size": c.greater_than(2.0),
@@ -79,6 +84,10 @@ class ParamLayout:
             "x_mean": c.interval(-H + e, H - e), "y_mean": c.interval(-H + e, H - e),
             "size": c.greater_than(2.0),
         }
+        if self.crosstalk:  # crosstalk.py:429-438
+            cons["alpha_mean"] = c.simplex
+            cons["alpha_size"] = c.positive
+        return cons
 
     def constrained(self, flat):
         cons = self.constraints()

@@ -7,6 +7,7 @@ import subprocess
 import torch
 
 from oracle.cosmos import CosmosOracle, OracleData
+from oracle.crosstalk import CrosstalkOracle
 from tapqir_amd import _lib
 from tapqir_amd.models.engine import CosmosEngine
 from tapqir_amd.utils.dataset import CosmosDataset
@@ -39,6 +40,7 @@ def load_hostcheck():
     lib.hc_globals_size.restype = C.c_int64
     lib.hc_gbase_size.restype = C.c_int64
     lib.hc_ksmogn_log_prob.argtypes = [C.POINTER(_lib.KsmognArgs)]
+    lib.hc_ksmogn_crosstalk_log_prob.argtypes = [C.POINTER(_lib.XtalkArgs)]
     lib.hc_image_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     lib.hc_image_stats.restype = None
     lib.hc_cosmos_probs.argtypes = [C.POINTER(_lib.ProbsArgs)]
@@ -79,9 +81,9 @@ def make_dataset(N=4, F=6, C=1, P=14, K=2, seed=0, offsets="sim", mask=None):
     return d
 
 
-def make_oracle(d, K, perturb=0.3, seed=1, eps=EPS32):
+def make_oracle(d, K, perturb=0.3, seed=1, eps=EPS32, crosstalk=False):
     od = OracleData(d.images, d.xy, d.is_ontarget, d.offset.samples, d.offset.weights, mask=d.mask)
-    o = CosmosOracle(od, K=K, eps=eps)
+    o = (CrosstalkOracle if crosstalk else CosmosOracle)(od, K=K, eps=eps)
     p = o.init_parameters()
     g = torch.Generator().manual_seed(seed)
     for u in p.values():
@@ -106,6 +108,8 @@ def fp32_latents(o, ndx, fdx, seed=3):
         lat = o.sample_guide(o.params, ndx, fdx)
     lat32 = {k: v.float().double() for k, v in lat.items()}
     lat32["pi"] = torch.stack([1 - lat32["pi"][..., 1], lat32["pi"][..., 1]], -1)
+    if "alpha" in lat32:  # the kernels carry both components in fp32; keep them summing to one as drawn
+        lat32["alpha"] = torch.stack([lat32["alpha"][..., 0], lat32["alpha"][..., 1]], -1)
     with torch.no_grad():
         dists = o._guide_dists(o.constrained(o.params), ndx, fdx)
         base = o.base_draws(lat32, dists)
@@ -127,6 +131,8 @@ def put_latents(eng, lat32, base):
     Q = eng.C
     gb[2:2 + Q] = base["lamda_g"]
     gb[6:6 + 2 * Q] = base["pi_x"].reshape(-1)
+    if "alpha_x" in base:  # double alpha_x[2][2] follows pi_x[4][2]
+        gb[14:18] = base["alpha_x"].reshape(-1)
     eng.gbase.copy_(gb)
 
 
@@ -161,4 +167,6 @@ def read_engine_latents(eng, nb, fb):
         "lamda": g[5:5 + C].clone(),
         "pi": torch.stack([1 - g[9:9 + C], g[9:9 + C]], -1),
     }
+    if getattr(eng, "crosstalk", False):  # float alpha[2][2] follows c[4]
+        out["alpha"] = g[21:25].clone().view(2, 2)
     return out

@@ -11,6 +11,7 @@
 
 #include "../../tapqir_amd/csrc/tq_bodies.h"
 #include "../../tapqir_amd/csrc/tq_pixel.h"
+#include "../../tapqir_amd/csrc/tq_xtalk.h"
 
 extern "C" {
 
@@ -229,11 +230,46 @@ int hc_ksmogn_log_prob(const tq_ksmogn_args* a) {
   return 0;
 }
 
+}  // extern "C"
+
+template <int K>
+static void xtalk_host(const tq_xtalk_args& a) {
+  const bool bwd = a.g_background != nullptr;
+  const int64_t Bg = (int64_t)a.nb * a.fb;
+  const float g = a.gain[0], rg = 1.0f / g, ln_g = logf(g);
+  TqOffsetInfo h;
+  tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
+  for (int64_t gi = 0; gi < Bg; ++gi) {
+    TqXtGroup<K> G;
+    tq_xtalk_load_group<K>(a, gi, bwd, &G);
+    TqXtAcc<K> A;
+    tq_xt_acc_zero<K>(A);
+    const bool fast = fminf(G.b[0], G.b[1]) * rg >= TQ_FAST_ALPHA;
+    if (bwd) {
+      if (fast) tq_xtalk_pixels<K, true, true>(a, G, h, 0, 1, g, rg, ln_g, A);
+      else tq_xtalk_pixels<K, true, false>(a, G, h, 0, 1, g, rg, ln_g, A);
+      tq_xtalk_finish<K, true>(a, gi, G, A, rg);
+    } else {
+      if (fast) tq_xtalk_pixels<K, false, true>(a, G, h, 0, 1, g, rg, ln_g, A);
+      else tq_xtalk_pixels<K, false, false>(a, G, h, 0, 1, g, rg, ln_g, A);
+      tq_xtalk_finish<K, false>(a, gi, G, A, rg);
+    }
+  }
+}
+
+extern "C" {
+
+int hc_ksmogn_crosstalk_log_prob(const tq_xtalk_args* a) {
+  if (a->K == 1) xtalk_host<1>(*a);
+  else xtalk_host<2>(*a);
+  return 0;
+}
+
 int64_t hc_globals_size(void) { return (int64_t)sizeof(TqGlobals); }
 int64_t hc_gbase_size(void) { return (int64_t)sizeof(TqGlobalBase); }
 
 void hc_cosmos_sample_globals(const tq_cosmos_args* a) {
-  for (int s = 0; s < TQ_NGSITES(a->C); ++s) tq_body_sample_globals(*a, s);
+  for (int s = 0; s < tq_num_gsites(*a); ++s) tq_body_sample_globals(*a, s);
 }
 void hc_cosmos_sample_locals(const tq_cosmos_args* a) {
   const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
@@ -245,7 +281,7 @@ void hc_cosmos_sample_locals(const tq_cosmos_args* a) {
 template <int K>
 static void units_host(const tq_cosmos_args& a, double* sums) {
   const int64_t B = tq_batch_units(a);
-  const int nq = 3 + 3 * a.C;
+  const int nq = tq_num_gsum(a);
   float part[3 + 3 * TQ_MAXQ];
   for (int64_t i = 0; i < B; ++i) {
     tq_body_unit<K>(a, i, part);
@@ -279,8 +315,27 @@ void hc_cosmos_elbo_grads(const tq_cosmos_args* a) {
   k.g_y = a->pix + (int64_t)(M + 2 + 3 * K) * B;
   k.nb = a->nb; k.fb = a->fb; k.C = a->C; k.F = a->F; k.P = a->P; k.K = K; k.O = a->O;
   k.scale = a->scale;
-  hc_ksmogn_log_prob(&k);
-  const int nq = 3 + 3 * a->C;
+  if (a->crosstalk) {
+    tq_xtalk_args x;
+    memset(&x, 0, sizeof(x));
+    x.images = a->images; x.xy = a->xy; x.ndx = a->ndx; x.fdx = a->fdx;
+    x.background = k.background; x.height = k.height; x.width = k.width; x.x = k.x; x.y = k.y;
+    x.gain = k.gain;
+    x.alpha = &((const TqGlobals*)a->globals)->alpha[0][0];
+    x.offset_samples = a->offset_samples; x.offset_logits = a->offset_logits;
+    x.m_logit = a->params; x.m_kstride = U; x.aoi_mask = a->aoi_mask;
+    x.ll = a->pix;
+    x.ell_excess = a->pix + (int64_t)(M + 2 + 4 * K) * B;
+    x.g_alpha = a->pix + (int64_t)(M + 3 + 4 * K) * B;
+    x.g_background = k.g_background; x.g_gain = k.g_gain;
+    x.g_height = k.g_height; x.g_width = k.g_width; x.g_x = k.g_x; x.g_y = k.g_y;
+    x.nb = a->nb; x.fb = a->fb; x.C = a->C; x.F = a->F; x.P = a->P; x.K = K; x.O = a->O;
+    x.scale = a->scale;
+    hc_ksmogn_crosstalk_log_prob(&x);
+  } else {
+    hc_ksmogn_log_prob(&k);
+  }
+  const int nq = tq_num_gsum(*a);
   std::vector<double> sums(nq, 0.0);
   switch (K) {
     case 1: units_host<1>(*a, sums.data()); break;
@@ -305,11 +360,11 @@ void hc_cosmos_elbo_grads(const tq_cosmos_args* a) {
 
 void hc_cosmos_globals_grad(const tq_cosmos_args* a) {
   double eg = 0.0;
-  for (int s = 0; s < TQ_NGSITES(a->C); ++s) eg += tq_body_globals_grad(*a, s);
+  for (int s = 0; s < tq_num_gsites(*a); ++s) eg += tq_body_globals_grad(*a, s);
   a->elbo_out[0] = a->gsum[TQ_GS_ELBO] + (double)a->global_weight * eg;
 }
 void hc_cosmos_adam(const tq_cosmos_args* a) {
-  const int64_t total = (int64_t)TQ_NLOCAL(a->K) * tq_num_units(*a) + 2 * (int64_t)a->Nt * a->C + TQ_NGLOBAL(a->C);
+  const int64_t total = tq_num_params(*a);
   for (int64_t j = a->fuse_adam ? tq_aoi_base(*a) : 0; j < total; ++j) tq_body_adam(*a, j);
 }
 

@@ -26,7 +26,7 @@ def _given_inputs(o, eng, lats, nd, fd):
     U = o.data.Nt * o.data.F * o.data.C
     with torch.no_grad():
         dists = o._guide_dists(o.constrained(o.params), nd, fd)
-        gb = torch.zeros(S, 14, dtype=torch.float64)
+        gb = torch.zeros(S, eng.gbase.numel(), dtype=torch.float64)  # sizeof(TqGlobalBase) / 8
         xy = torch.zeros(S, 2 * K, U, dtype=torch.float32)
         for s, lat in enumerate(lats):
             base = o.base_draws(lat, dists)
