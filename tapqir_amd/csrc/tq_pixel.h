@@ -179,3 +179,39 @@ TQ_HD void tq_pix_multi_offset(float D, const float* mu, const float* samples, c
   }
   for (int mi = 0; mi < M; ++mi) tq_mo_finish(FAST, mu[mi], vs[mi], vhi, S0[mi], S1[mi], S2[mi], h, g, rg, ln_g, &lp[mi], &da[mi], &gq[mi]);
 }
+
+// One pixel, every combination, ONE offset (no data statistics needed: used by the crosstalk kernel, whose
+// combinations all carry spots in every channel).  Same Binet form as above with S0 = 1:
+//   log p = [ln w - ln sqrt(2 pi) - ln v] + alpha phi(v / mu) + (1/2) ln alpha - S(alpha).
+template <int M, bool BWD, bool FAST>
+TQ_HD void tq_pix_single_offset(float D, const float* mu, float off, float lw, float g, float rg, float ln_g, float* lp,
+                                float* da, float* gq) {
+  const float v = D - off;
+  if (!(v > 0.0f)) {
+    for (int mi = 0; mi < M; ++mi) {
+      lp[mi] = -INFINITY;
+      da[mi] = 0.0f;
+      gq[mi] = 0.0f;
+    }
+    return;
+  }
+  const float lnv = TQ_FLOG(v);
+  const float c0 = lw - TQ_LN_SQRT_2PI - lnv;
+  const float vg = v * rg;
+  for (int mi = 0; mi < M; ++mi) {
+    const float r = TQ_FRCP(mu[mi]);
+    const float rho = v * r;
+    const float lnrho = TQ_LN2 * TQ_FLOG2(rho);
+    const float alpha = mu[mi] * rg, ralpha = g * r;
+    const float lnalpha = lnv - lnrho - ln_g;
+    float S, dS;
+    if (FAST) tq_binet_fast(ralpha, &S, &dS);
+    else tq_binet(alpha, lnalpha, ralpha, &S, &dS);
+    lp[mi] = c0 + alpha * (lnrho + 1.0f - rho) + 0.5f * lnalpha - S;
+    if (BWD) {
+      const float d = lnrho + 0.5f * ralpha - dS;
+      da[mi] = d;
+      gq[mi] = alpha * (d + 1.0f) - vg;
+    }
+  }
+}

@@ -114,6 +114,7 @@ TQ_HD void tq_xtalk_pixels(const tq_xtalk_args& a, const TqXtGroup<K>& G, const 
                            float rg, float ln_g, TqXtAcc<K>& A) {
   constexpr int Q = TQ_XT_Q, NS = Q * K, MJ = 1 << NS, CH = (MJ < TQ_XT_CHUNK ? MJ : TQ_XT_CHUNK);
   const int P = a.P, npix = P * P;
+  const float off0 = a.offset_samples[0], lw0 = a.offset_logits[0];
   float nl2[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) nl2[s] = -0.5f * TQ_FRCP(G.w[s] * G.w[s]) * TQ_LOG2E;
@@ -149,7 +150,8 @@ TQ_HD void tq_xtalk_pixels(const tq_xtalk_args& a, const TqXtGroup<K>& G, const 
           for (int s = 0; s < NS; ++s)
             if (((base + e) >> s) & 1) mu[e] += spot[s];
         }
-        tq_pix_multi_offset<CH, BWD, FAST>(D, mu, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, lp, da, gq);
+        if (a.O == 1) tq_pix_single_offset<CH, BWD, FAST>(D, mu, off0, lw0, g, rg, ln_g, lp, da, gq);
+        else tq_pix_multi_offset<CH, BWD, FAST>(D, mu, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, lp, da, gq);
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
           A.ll[base + e] += lp[e];

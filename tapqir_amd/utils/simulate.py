@@ -9,6 +9,7 @@ sampled directly with a seeded ``torch.Generator`` on the requested device:
   z ~ Bernoulli(pi) on-target else 0; theta ~ U{1..K} if z else 0; m_k ~ Bernoulli(probs_m[theta, k])
   x_k, y_k ~ AffineBeta(0, size[theta == k+1], -(P+1)/2, (P+1)/2), size = [2, ((P+1)/(2 proximity))^2 - 1]
   image = floor(Gamma(mu / gain, 1 / gain) + offset), mu = background + sum_k m_k h N2(.)
+  (crosstalk: mu_c = background + sum_q alpha[q, c] sum_k m_qk h N2(.), params["alpha"] = (Q, C) matrix)
 """
 
 import numpy as np
@@ -35,8 +36,13 @@ def simulate(model, N: int, F: int, C: int = 1, P: int = 14, seed: int = 0, para
     """
     K = model if isinstance(model, int) else model.K
     device = torch.device("cpu") if isinstance(model, int) else torch.device(model.device)
-    if "pi" not in params or "alpha" in params:
-        raise NotImplementedError("only the cosmos (time-independent, no cross-talk) law is generated here")
+    if "pi" not in params:
+        raise NotImplementedError("only the time-independent laws (cosmos, crosstalk) are generated here")
+    # crosstalk simulations (simulate.py:27-31, 118-123): params["alpha"] is the (Q, C) matrix of the fraction of dye
+    # q's signal seen in channel c (crosstalk.py:262-281)
+    alpha = None
+    if "alpha" in params:
+        alpha = torch.as_tensor(params["alpha"], dtype=torch.float32, device=device).reshape(C, C)
     gen = torch.Generator(device=device).manual_seed(seed)
     dt = torch.float32
     H = (P + 1) / 2
@@ -66,7 +72,10 @@ def simulate(model, N: int, F: int, C: int = 1, P: int = 14, seed: int = 0, para
         sl = slice(s, min(N, s + chunk))
         tl = target[sl].to(device)[..., None, :]
         spots = gaussian_spots(h.expand_as(x[sl]), w.expand_as(x[sl]), x[sl], y[sl], tl, P, m[sl].to(dt))
-        mu = params["background"] + spots.sum(-3)
+        mu = spots.sum(-3)  # (n, F, Q, P, P)
+        if alpha is not None:
+            mu = torch.einsum("qc,nfqij->nfcij", alpha, mu)
+        mu = params["background"] + mu
         val = _std_gamma(mu / gain, gen) * gain
         val = val.clamp(min=torch.finfo(dt).tiny)
         images[sl] = (val + params["offset"]).floor().cpu()
