@@ -43,6 +43,21 @@ def step_bytes_per_unit(K, P):
     return 4 * P * P + 8 + 6 * 4 * (8 * K + 2)
 
 
+def pmc_traffic(K, P, units, backward):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 correction applied; profiles/r01_pmc_traffic.json says how).  PMC collection cannot run
+    inside this process, so the figure is the measured one for this exact kernel and shape, else None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    if (d.get("K"), d.get("P"), d.get("units")) != (K, P, units):
+        return None
+    k = d["kernels"].get(f"tq_ksmogn_il2_kernel<{K}, {P}, {'true' if backward else 'false'}>")
+    return None if k is None else k["traffic_bytes"]
+
+
 def time_pixel_kernel(eng, launches, backward):
     """Average duration of the fused render+log-prob kernel, HIP events on its launch stream."""
     from tapqir_amd import _lib
@@ -248,7 +263,9 @@ def main():
             bpu = fwd_bytes_per_unit(K, P)
             ach = N * F * bpu / t_fb / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic(K, P, N * F, True) if args.offsets == "sim" else None,
+                               "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json); algorithmic = bytes_per_unit x units_per_launch",
                                "kernel": "tq_ksmogn_il2_kernel<K,P,bwd> (fused render + log-prob + pathwise grads; packed lane-per-unit)",
                                "bytes_per_unit": bpu, "units_per_launch": N * F, "avg_launch_ms": t_fb * 1e3,
                                "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": N * F * bpu / t_f / 1e9,
