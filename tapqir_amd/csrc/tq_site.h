@@ -65,11 +65,14 @@ TQ_HD void tq_gamma_logpdf(float v, float loc, float beta, float* lp, float* d_v
   const float alpha = loc * beta;
   const float rloc = TQ_FRCP(loc);
   const float rho = v * rloc;
-  const float lrho = log1pf((v - loc) * rloc);
+  const float lnv = TQ_FLOG(v);
+  // ln(v / loc): log1p near the mean (no cancellation in phi), difference of logs far from it (a draw many orders of
+  // magnitude below loc, as Gamma draws with concentration < 1 are, must not round (v - loc) / loc to -1)
+  const float lrho = (fabsf(v - loc) < 0.5f * loc) ? log1pf((v - loc) * rloc) : lnv - TQ_FLOG(loc);
   const float lna = TQ_FLOG(alpha), ra = TQ_FRCP(alpha);
   float S, dS;
   tq_binet(alpha, lna, ra, &S, &dS);
-  *lp = -TQ_FLOG(v) + alpha * (lrho + 1.0f - rho) + 0.5f * lna - TQ_LN_SQRT_2PI - S;
+  *lp = -lnv + alpha * (lrho + 1.0f - rho) + 0.5f * lna - TQ_LN_SQRT_2PI - S;
   *d_v = (alpha - 1.0f) * TQ_FRCP(v) - beta;
   *d_alpha = lrho + 0.5f * ra - dS;  // = ln beta + ln v - digamma(alpha)
   *d_beta = loc - v;                 // = alpha / beta - v

@@ -70,3 +70,37 @@ def test_unperturbed_initial_parameters():
     gv = eng.named("grad")
     for n, ref in g_o.items():
         assert rel_err(gv[n].double().reshape(ref.shape), ref) < 1e-4, n
+
+
+def test_extreme_gamma_draw_far_below_the_mean():
+    """A height draw many orders of magnitude below h_loc (Gamma concentration < 1, as h_beta adapts during a fit)
+    must keep log q and the gradients finite and equal to the oracle's (regression: ln(v/loc) via log1p rounded to -inf)."""
+    import math
+
+    hc = load_hostcheck()
+    K = 2
+    d = make_dataset(N=2, F=3, K=K)
+    o = make_oracle(d, K, perturb=0.2)
+    o.params["h_loc"].data[0, 0, 0, 0] = math.log(394.0)
+    o.params["h_beta"].data[0, 0, 0, 0] = math.log(0.00197)
+    for u in o.params.values():
+        u.data = u.data.float().double()
+    eng = CosmosEngine(d, K=K, device="cpu", lib=hc)
+    oracle_to_engine(o, eng)
+    nd, fd = torch.arange(2), torch.arange(3)
+    lat32, _ = fp32_latents(o, nd, fd)
+    lat32["height"][0, 0, 0, 0] = torch.tensor(2.5122093916252197e-07).float().double()
+    with torch.no_grad():
+        base = o.base_draws(lat32, o._guide_dists(o.constrained(o.params), nd, fd))
+    elbo_o, g_o = oracle_grads(o, nd, fd, base)
+    a = eng.make_args(None, None, draw_globals=False)
+    put_latents(eng, lat32, base)
+    for stage in GIVEN_STAGES:
+        eng.call(stage, a)
+    elbo_k = float(eng.elbo_out[0])
+    assert math.isfinite(elbo_k) and abs(elbo_k - elbo_o) <= 1e-5 * abs(elbo_o), (elbo_k, elbo_o)
+    gv = eng.named("grad")
+    for n, ref in g_o.items():
+        got = gv[n].double().reshape(ref.shape)
+        assert torch.isfinite(got).all(), n
+        assert rel_err(got, ref) < 1e-4, (n, rel_err(got, ref))
