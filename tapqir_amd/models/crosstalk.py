@@ -6,8 +6,8 @@ Differences from ``cosmos`` (see ``oracle/crosstalk.py`` for the closed form tha
 one data site per AOI-frame with event shape (C, P, P) whose channel ``c`` sees the spots of every dye ``q``
 scaled by ``alpha[q, c]`` (crosstalk.py:262-281), a global Dirichlet site ``alpha`` (80-87, 279-284) with
 parameters ``alpha_mean`` (Q, C) / ``alpha_size`` (Q, 1) (429-438), and 2^(K Q) joint spot-presence
-combinations in the guide-side enumeration.  Implemented for Q = C = 2 and K <= 2 (the reference's code
-indexes dyes and channels alike, crosstalk.py:246-261).
+combinations in the guide-side enumeration.  Implemented for Q = C = 2 with K <= 2, and for Q = C = 1 (where it
+coincides with cosmos; the reference's code indexes dyes and channels alike, crosstalk.py:246-261).
 """
 
 import torch

@@ -49,9 +49,14 @@ class CosmosEngine:
                     f"(device={device!r} requested); there is no CPU path")
             lib = _lib.load()
         self.lib = lib
-        self.crosstalk = bool(crosstalk)
-        if self.crosstalk and (int(data.images.shape[2]) != 2 or int(K) > 2):
-            raise ValueError("the crosstalk model is implemented for Q = C = 2 dyes/channels and K <= 2 "
+        # With one dye and one channel the crosstalk model IS cosmos (alpha = [[1]] is a one-component Dirichlet:
+        # constant draw, zero log-density, no gradient; the reference's smoke test runs this case,
+        # test/test_tapqir.py:27-30): the cosmos kernels run and alpha_mean / alpha_size are inert parameters.
+        nch = int(data.images.shape[2])
+        self.crosstalk = bool(crosstalk) and nch > 1
+        self.layout_crosstalk = bool(crosstalk)
+        if self.crosstalk and (nch != 2 or int(K) > 2):
+            raise ValueError("the crosstalk model is implemented for Q = C <= 2 dyes/channels and K <= 2 "
                              "(2^(K Q) joint spot-presence combinations; tapqir/models/crosstalk.py is experimental "
                              "upstream and indexes dyes and channels alike)")
         self.K = int(K)
@@ -93,7 +98,7 @@ class CosmosEngine:
                 _lib.check(lib.tq_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples),
                                               _lib.ptr(self.pixstats), U, self.P,
                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tq_image_stats")
-        self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps, crosstalk=self.crosstalk)
+        self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps, crosstalk=self.layout_crosstalk)
         n = self.layout.total
         self.params = torch.zeros(n, dtype=f32, device=dev)
         self.grad = torch.zeros(n, dtype=f32, device=dev)

@@ -31,7 +31,7 @@ class ParamLayout:
         self.U = Nt * F * C
         self.n_local = (8 * K + 2) * self.U
         self.n_aoi = 2 * Nt * C
-        self.n_global = 4 + 5 * C + (3 * C if crosstalk else 0)
+        self.n_global = 4 + 5 * C + (C * C + C if crosstalk else 0)  # alpha_mean (Q, C), alpha_size (Q, 1)
         self.total = self.n_local + self.n_aoi + self.n_global
         self.eps = eps
 
@@ -57,7 +57,7 @@ class ParamLayout:
         s["pi_size"] = (g + 4 + 4 * Q, (Q, 1))
         if self.crosstalk:
             s["alpha_mean"] = (g + 4 + 5 * Q, (Q, C))
-            s["alpha_size"] = (g + 4 + 7 * Q, (Q, 1))
+            s["alpha_size"] = (g + 4 + 5 * Q + Q * C, (Q, 1))
         return s
 
     def views(self, flat):
