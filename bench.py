@@ -151,17 +151,24 @@ def main():
     ap.add_argument("--offsets", default="sim", choices=["sim", "hist"])
     ap.add_argument("--model", default="cosmos", choices=["cosmos", "crosstalk"],
                     help="crosstalk = BASELINE config c4 (Q = C = 2, alpha = [[.9,.1],[.2,.8]]); not the headline metric")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the multi-GPU code path (process group, staged step, all-reduce) with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -190,7 +197,7 @@ def main():
     eng.layout.set_constrained(eng.params, (crosstalk_initial_values if xt else initial_values)(eng, data))
 
     allreduce = None
-    if world > 1:
+    if use_dist:
         def allreduce(t):
             dist.all_reduce(t)
 
@@ -199,7 +206,7 @@ def main():
             eng.step(ndx, fdx, allreduce=allreduce)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -217,7 +224,7 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -276,7 +283,7 @@ def main():
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(data, K, min(10, N), min(512, F))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

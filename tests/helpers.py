@@ -142,7 +142,7 @@ def oracle_grads(o, ndx, fdx, base):
     lat = o.latents_from_base(o.params, ndx, fdx, base)
     elbo = o.elbo(o.params, ndx, fdx, lat)
     elbo.backward()
-    return float(elbo), {n: (u.grad.clone() if u.grad is not None else torch.zeros_like(u)) for n, u in o.params.items()}
+    return float(elbo.detach()), {n: (u.grad.clone() if u.grad is not None else torch.zeros_like(u)) for n, u in o.params.items()}
 
 
 def rel_err(a, b):
