@@ -106,6 +106,10 @@ int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
  * ------------------------------------------------------------------------------------- */
 typedef struct {
   const float* images;         /* (Nt, F, C, P, P) */
+  const float* images_il;      /* tq_images_interleave_n(images, ., Nt*F, C*P*P): one (C, P, P) tile per AOI-frame, or NULL.
+                                  With pixstats, O == 1 and a contiguous batch of at least il_min_units AOI-frames the
+                                  packed lane-per-AOI-frame kernel runs */
+  const float* pixstats;       /* [3][Nt*F*C] tq_image_stats of the (n, f, c) tiles, or NULL */
   const float* xy;             /* (Nt, F, C, 2) */
   const int32_t* ndx;          /* [nb] or NULL */
   const int32_t* fdx;          /* [fb] or NULL */
@@ -134,6 +138,8 @@ typedef struct {
   int64_t m_kstride;           /* = Nt*F*Q */
   int32_t nb, fb, C, F;
   int32_t P, K, O;
+  int32_t nb_full;             /* Nt of the dataset behind images_il */
+  int32_t il_min_units;        /* AOI-frames from which the packed kernel is used */
   float scale;
 } tq_xtalk_args;
 
@@ -145,6 +151,9 @@ int tq_ksmogn_crosstalk_log_prob(const tq_xtalk_args* a, void* stream);
  * `out` must hold tq_interleaved_floats(U, P) floats. */
 int64_t tq_interleaved_floats(int64_t U, int32_t P);
 int tq_images_interleave(const float* images, float* images_il, int64_t U, int32_t P, void* stream);
+/* the same for tiles of `npix` floats (crosstalk: one (C, P, P) tile per AOI-frame) */
+int64_t tq_interleaved_floats_n(int64_t U, int32_t npix);
+int tq_images_interleave_n(const float* images, float* images_il, int64_t U, int32_t npix, void* stream);
 
 /* Per-unit data statistics for a single camera offset `offset[0]` (device scalar): with v = D - offset,
  *   pixstats[0][u] = sum_pix v,  pixstats[1][u] = sum_pix ln v,  pixstats[2][u] = #pixels with v <= 0

@@ -69,7 +69,8 @@ class XtalkArgs(C.Structure):
     """``tq_xtalk_args`` (include/tapqir_hip.h)."""
 
     _fields_ = [
-        ("images", C.c_void_p), ("xy", C.c_void_p), ("ndx", C.c_void_p), ("fdx", C.c_void_p),
+        ("images", C.c_void_p), ("images_il", C.c_void_p), ("pixstats", C.c_void_p), ("xy", C.c_void_p),
+        ("ndx", C.c_void_p), ("fdx", C.c_void_p),
         ("background", C.c_void_p), ("height", C.c_void_p), ("width", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
         ("gain", C.c_void_p), ("alpha", C.c_void_p), ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
         ("gout", C.c_void_p), ("m_logit", C.c_void_p), ("aoi_mask", C.c_void_p),
@@ -79,6 +80,7 @@ class XtalkArgs(C.Structure):
         ("m_kstride", C.c_int64),
         ("nb", C.c_int32), ("fb", C.c_int32), ("C", C.c_int32), ("F", C.c_int32),
         ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
+        ("nb_full", C.c_int32), ("il_min_units", C.c_int32),
         ("scale", C.c_float),
     ]
 
@@ -97,7 +99,7 @@ class ProbsArgs(C.Structure):
 # every symbol include/tapqir_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "tq_version", "tq_last_error", "tq_ksmogn_log_prob", "tq_ksmogn_crosstalk_log_prob", "tq_crosstalk_param_count",
-    "tq_interleaved_floats", "tq_images_interleave", "tq_image_stats",
+    "tq_interleaved_floats", "tq_interleaved_floats_n", "tq_images_interleave_n", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_join", "tq_cosmos_probs",
@@ -134,6 +136,10 @@ def load():
     lib.tq_ksmogn_crosstalk_log_prob.restype = C.c_int
     lib.tq_interleaved_floats.restype = C.c_int64
     lib.tq_interleaved_floats.argtypes = [C.c_int64, C.c_int32]
+    lib.tq_interleaved_floats_n.restype = C.c_int64
+    lib.tq_interleaved_floats_n.argtypes = [C.c_int64, C.c_int32]
+    lib.tq_images_interleave_n.restype = C.c_int
+    lib.tq_images_interleave_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.tq_images_interleave.restype = C.c_int
     lib.tq_images_interleave.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.tq_image_stats.restype = C.c_int

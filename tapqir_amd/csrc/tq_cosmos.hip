@@ -272,6 +272,8 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
     // per-unit routine expects ll, two more row groups follow the cosmos block of pix
     tq_xtalk_args x = {};
     x.images = a->images; x.xy = a->xy; x.ndx = a->ndx; x.fdx = a->fdx;
+    x.images_il = a->images_il;  // crosstalk: interleaved (C, P, P) tiles per AOI-frame (tq_images_interleave_n)
+    x.pixstats = a->pixstats; x.nb_full = a->Nt; x.il_min_units = a->il_min_units;
     x.background = k.background; x.height = k.height; x.width = k.width; x.x = k.x; x.y = k.y;
     x.gain = k.gain;
     x.alpha = &((const TqGlobals*)a->globals)->alpha[0][0];

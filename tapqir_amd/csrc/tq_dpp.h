@@ -1,4 +1,5 @@
-// tq_dpp.h -- cross-lane sums over the 16 lanes of a DPP row (device only).
+// tq_dpp.h -- device-only helpers: cross-lane sums over the 16 lanes of a DPP row, float2 values for the packed
+// v_pk_{fma,mul,add}_f32 instructions.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,3 +15,10 @@ __device__ __forceinline__ float tq_group_sum16(float v) {
   v += tq_dpp<0x140>(v);  // row_mirror            -> sum of 16, in every lane
   return v;
 }
+
+// two FP32 values per lane that the compiler maps onto packed instructions (two operations per lane and issue slot)
+typedef float tq_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tq_f2 tq2(float a) { return (tq_f2){a, a}; }
+__device__ __forceinline__ tq_f2 tq2_rcp(tq_f2 a) { return (tq_f2){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ tq_f2 tq2_log2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)}; }
+__device__ __forceinline__ tq_f2 tq2_exp2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }

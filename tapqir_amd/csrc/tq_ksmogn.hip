@@ -518,11 +518,6 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il_kernel(const tq_ksmogn_args 
 // group of 4 pixels is re-loaded, right after its last use, with the same group of the next body
 // (one body = 28 or 20 pixels of latency cover, G float4 registers).
 // =============================================================================================
-typedef float tq_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ tq_f2 tq2(float a) { return (tq_f2){a, a}; }
-__device__ __forceinline__ tq_f2 tq2_rcp(tq_f2 a) { return (tq_f2){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
-__device__ __forceinline__ tq_f2 tq2_log2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)}; }
-__device__ __forceinline__ tq_f2 tq2_exp2(tq_f2 a) { return (tq_f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
 
 // Running sums of the packed loop.  COLACC: the x-moments are kept as per-COLUMN sums (one fma per pixel pair
 // and spot instead of three) and folded with the column coordinates once per unit; used when the K*P/2
@@ -1135,9 +1130,21 @@ extern "C" int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream) {
   }
 }
 
-extern "C" int64_t tq_interleaved_floats(int64_t U, int32_t P) {
-  const int64_t npix4 = ((int64_t)P * P + 3) / 4;
+extern "C" int64_t tq_interleaved_floats_n(int64_t U, int32_t npix) {
+  const int64_t npix4 = ((int64_t)npix + 3) / 4;
   return ((U + 63) / 64) * npix4 * 256;
+}
+extern "C" int64_t tq_interleaved_floats(int64_t U, int32_t P) { return tq_interleaved_floats_n(U, P * P); }
+
+extern "C" int tq_images_interleave_n(const float* images, float* images_il, int64_t U, int32_t npix, void* stream) {
+  if (!images || !images_il || U < 1 || npix < 4) {
+    tq_set_error("tq_images_interleave_n: bad argument");
+    return TQ_ERR_ARG;
+  }
+  const int64_t total4 = tq_interleaved_floats_n(U, npix) / 4;
+  hipLaunchKernelGGL(tq_interleave_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     images, images_il, U, npix, total4);
+  return launch_status("tq_interleave_kernel");
 }
 
 extern "C" int tq_images_interleave(const float* images, float* images_il, int64_t U, int32_t P, void* stream) {

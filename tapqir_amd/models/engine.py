@@ -76,19 +76,21 @@ class CosmosEngine:
         # tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the
         # library so that any C caller gets the same layout
         self.images_il = None
-        if not self._hostcheck and not self.crosstalk:
-            U = self.Nt * self.F * self.C
-            n_il = int(lib.tq_interleaved_floats(U, self.P))
+        if not self._hostcheck:
+            # cosmos: one (P, P) tile per unit (n, f, c); crosstalk: one (C, P, P) tile per AOI-frame (n, f)
+            tiles = self.Nt * self.F * (1 if self.crosstalk else self.C)
+            npix = self.P * self.P * (self.C if self.crosstalk else 1)
+            n_il = int(lib.tq_interleaved_floats_n(tiles, npix))
             self.images_il = torch.empty(n_il, dtype=f32, device=dev)
-            _lib.check(lib.tq_images_interleave(_lib.ptr(self.images), _lib.ptr(self.images_il), U, self.P,
-                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-                       "tq_images_interleave")
+            _lib.check(lib.tq_images_interleave_n(_lib.ptr(self.images), _lib.ptr(self.images_il), tiles, npix,
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "tq_images_interleave_n")
         off_s, off_l = merge_offsets(data.offset.samples, data.offset.weights)
         self.offset_samples, self.offset_logits = off_s.to(dev), off_l.to(dev)
         self.O = int(off_s.numel())
         # per-unit data statistics of the single-offset formulation (sum v, sum ln v, #masked pixels)
         self.pixstats = None
-        if self.O == 1 and not self.crosstalk:
+        if self.O == 1:
             U = self.Nt * self.F * self.C
             self.pixstats = torch.empty(3 * U, dtype=f32, device=dev)
             if self._hostcheck:

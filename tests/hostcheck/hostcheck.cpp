@@ -319,6 +319,7 @@ void hc_cosmos_elbo_grads(const tq_cosmos_args* a) {
     tq_xtalk_args x;
     memset(&x, 0, sizeof(x));
     x.images = a->images; x.xy = a->xy; x.ndx = a->ndx; x.fdx = a->fdx;
+    x.nb_full = a->Nt;
     x.background = k.background; x.height = k.height; x.width = k.width; x.x = k.x; x.y = k.y;
     x.gain = k.gain;
     x.alpha = &((const TqGlobals*)a->globals)->alpha[0][0];

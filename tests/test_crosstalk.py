@@ -20,13 +20,15 @@ XT_CASES = [
 ]
 
 
-def run_xt_case(dkw, K, ndx, fdx, gpu, perturb=0.3):
+def run_xt_case(dkw, K, ndx, fdx, gpu, perturb=0.3, il_min_units=None):
     d = make_dataset(K=K, **dkw)
     o = make_oracle(d, K, perturb=perturb, crosstalk=True)
     if gpu:
         eng = CosmosEngine(d, K=K, device="cuda:0", crosstalk=True)
     else:
         eng = CosmosEngine(d, K=K, device="cpu", lib=load_hostcheck(), crosstalk=True)
+    if il_min_units is not None:
+        eng.il_min_units = il_min_units
     oracle_to_engine(o, eng)
     nd = torch.arange(d.images.shape[0]) if ndx is None else torch.tensor(ndx)
     fd = torch.arange(d.images.shape[1]) if fdx is None else torch.tensor(fdx)
@@ -149,3 +151,29 @@ def test_registry_names():
     assert set(models) == {"cosmos", "crosstalk", "cosmos+hmm"}  # tapqir/models/__init__.py:17-21
     with pytest.raises(NotImplementedError):
         models["cosmos+hmm"]()
+
+
+XT_IL_CASES = [  # contiguous full batches through the packed lane-per-AOI-frame kernel
+    ("K2", dict(N=3, F=4, C=2), 2),
+    ("K2_partial_wave_and_two_waves", dict(N=5, F=15, C=2), 2),      # 75 AOI-frames
+    ("K2_P20", dict(N=2, F=2, C=2, P=20), 2),
+    ("K2_masked_aoi", dict(N=3, F=2, C=2, mask=torch.tensor([True, False, True])), 2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dkw,K", XT_IL_CASES, ids=[c[0] for c in XT_IL_CASES])
+def test_gpu_packed_kernel_matches_oracle(name, dkw, K):
+    o, eng, elbo_o, g_o = run_xt_case(dkw, K, None, None, gpu=True, il_min_units=1)
+    assert eng.images_il is not None and eng.pixstats is not None
+    check(o, eng, elbo_o, g_o)
+
+
+@pytest.mark.gpu
+def test_gpu_packed_and_16_lane_kernels_agree():
+    outs = []
+    for il in (1, 1 << 30):
+        _, eng, _, _ = run_xt_case(dict(N=5, F=15, C=2), 2, None, None, gpu=True, il_min_units=il)
+        outs.append(eng.pix.cpu().double().clone())
+    scale = outs[1].abs().max()
+    assert (outs[0] - outs[1]).abs().max() <= 2e-5 * scale
