@@ -467,7 +467,8 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il_kernel(const tq_ksmogn_args 
   const int64_t i = live ? i_raw : (B - 1);  // idle lanes of the last wave shadow the last unit
   const int P = a.P, npix = P * P;
   const int npix4 = (npix + 3) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i_raw >> 6) * npix4) * 64 + (i_raw & 63);
+  // idle lanes of the last workgroup read the LAST tile too: the interleaved buffer ends with its 64-tile block
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i >> 6) * npix4) * 64 + (i & 63);
 
   const float g = a.gain[0];
   const float rg = TQ_FRCP(g);
@@ -609,7 +610,8 @@ __global__ __launch_bounds__(256, (K <= 2 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
   const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i_raw < B;
   const int64_t i = live ? i_raw : (B - 1);
-  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i_raw >> 6) * npix4) * 64 + (i_raw & 63);
+  // idle lanes of the last workgroup read the LAST tile too: the interleaved buffer ends with its 64-tile block
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i >> 6) * npix4) * 64 + (i & 63);
 
   const float g = a.gain[0];
   const float rg = TQ_FRCP(g);
@@ -945,7 +947,8 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il2m_kernel(const tq_ksmogn_arg
   const int64_t i = live ? i_raw : (B - 1);
   const int P = a.P, npix = P * P;
   const int npix4 = npix >> 2;
-  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i_raw >> 6) * npix4) * 64 + (i_raw & 63);
+  // idle lanes of the last workgroup read the LAST tile too: the interleaved buffer ends with its 64-tile block
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i >> 6) * npix4) * 64 + (i & 63);
 
   const float g = a.gain[0];
   const float rg = TQ_FRCP(g);

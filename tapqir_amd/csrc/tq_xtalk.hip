@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void tq_xtalk_il_kernel(const tq_xtalk_args
   const int P = a.P, npix = P * P;
   const int npix4c = npix >> 2;          // float4 groups per channel (P even)
   const int npix4 = 2 * npix4c;          // per AOI-frame tile
-  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((g_raw >> 6) * npix4) * 64 + (g_raw & 63);
+  // idle lanes of the last workgroup read the LAST tile too: the interleaved buffer ends with its 64-tile block
+  const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((g >> 6) * npix4) * 64 + (g & 63);
 
   const float gain = a.gain[0];
   const float rg = TQ_FRCP(gain);
