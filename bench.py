@@ -58,6 +58,22 @@ def pmc_traffic(K, P, units, backward):
     return None if k is None else k["traffic_bytes"]
 
 
+def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + write bytes per second, GB/s): what this box's HBM delivers to a plain
+    streaming kernel; quoted next to the nominal 8 TB/s peak."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def time_pixel_kernel(eng, launches, backward):
     """Average duration of the fused render+log-prob kernel, HIP events on its launch stream."""
     from tapqir_amd import _lib
@@ -280,6 +296,10 @@ def main():
                                "whole_step": {"bytes_per_unit": step_bytes_per_unit(K, P),
                                               "achieved": N * F * step_bytes_per_unit(K, P) / (ms_per_step * 1e-3) / 1e9,
                                               "frac": N * F * step_bytes_per_unit(K, P) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            bw = measured_copy_bandwidth(dev)
+            out["roofline"]["peak_measured_copy"] = bw
+            out["roofline"]["frac_of_measured_copy"] = ach / bw
+            out["roofline"]["forward_only"]["frac_of_measured_copy"] = out["roofline"]["forward_only"]["achieved"] / bw
             if not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(data, K, min(10, N), min(512, F))
         print(json.dumps(out), flush=True)

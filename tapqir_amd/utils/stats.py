@@ -3,8 +3,8 @@ Post-fit statistics (the part of tapqir/utils/stats.py:89-259 that `tapqir fit` 
 intervals of the variational posteriors (scipy), spot probabilities, classification scores against
 simulated labels, ``<name>_params.tpqr`` / ``<name>_summary.csv`` (/ ``.mat``).
 
-Runs once per fit on the host; rastergram plotting and the SNR / chi2 columns of the reference are not
-reproduced (outside the hot path).
+Runs once per fit on the host: credible intervals, SNR and chi2 (stats.py:29-86, 166-193), plot ranges, classification
+scores and p(specific) (194-226).  The rastergram PNGs of the reference (105-124) are not drawn.
 """
 
 import logging
@@ -41,6 +41,41 @@ def dirichlet_interval(conc, CI):
     return torch.as_tensor(ll), torch.as_tensor(ul), conc / conc.sum(-1, keepdim=True)
 
 
+def quantile(x, q):
+    """Linear-interpolation quantile of a 1-D tensor (pyro.ops.stats.quantile semantics)."""
+    xs = torch.sort(x.double().flatten())[0]
+    pos = q * (xs.numel() - 1)
+    lo, hi = int(np.floor(pos)), int(np.ceil(pos))
+    return xs[lo] + (xs[hi] - xs[lo]) * (pos - lo)
+
+
+def hpdi(x, prob):
+    """Narrowest interval holding ``prob`` of the samples (pyro.ops.stats.hpdi semantics)."""
+    xs = torch.sort(x.double().flatten())[0]
+    n = xs.numel()
+    k = int(prob * n)
+    left, right = xs[: n - k], xs[k:]
+    i = int(torch.argmin(right - left))
+    return left[i], right[i]
+
+
+def snr_and_chi2(data, height, width, x, y, target_locs, background, gain, offset_mean, offset_var, P):
+    """Signal-to-noise ratio of each spot and chi2 of the fitted image for the frames of one AOI (stats.py:29-86).
+
+    data (F, C, P, P); height/width/x/y (K, F, Q); target_locs (F, C, 2); background (F, C).
+    signal_k = sum_ij (D - b - offset_mean) N_k(i, j),  noise = sqrt(offset_var + b gain),  SNR = signal / noise;
+    chi2 = mean_ij (D - ideal - offset_mean)^2 / ideal,  ideal = b + sum_k h_k N_k."""
+    from tapqir_amd.distributions.util import gaussian_spots
+
+    g = gaussian_spots(height, width, x, y, target_locs, P)  # (K, F, Q, P, P): the last parameter dim acts as "K"
+    weights = g / height[..., None, None]
+    resid = data - background[..., None, None] - offset_mean
+    snr = (resid * weights).sum((-2, -1)) / (offset_var + background * gain).sqrt()
+    ideal = background[..., None, None] + g.sum(-5)
+    chi2 = ((data - ideal - offset_mean) ** 2 / ideal).mean((-1, -2))
+    return snr, chi2
+
+
 def save_stats(model, path, CI=0.95, save_matlab=False):
     import pandas as pd
 
@@ -55,6 +90,35 @@ def save_stats(model, path, CI=0.95, save_matlab=False):
             summary.loc[param, col] = v.item() if v.ndim == 0 else v.tolist()
 
     data = model.data
+    # plot ranges (stats.py:126-142)
+    tmask = ci_stats["theta_probs"] > 0.5
+    hmax = float(np.percentile(ci_stats["height"]["Mean"][tmask].numpy(), 99)) if bool(tmask.any()) else 1.0
+    bmax = float(np.percentile(ci_stats["background"]["Mean"].numpy().ravel(), 99))
+    for name, (lo, hi) in {"height": (-0.03 * hmax, 1.3 * hmax), "width": (0.5, 2.5), "x": (-9, 9), "y": (-9, 9),
+                           "background": (-0.03 * bmax, 1.3 * bmax)}.items():
+        ci_stats[name]["vmin"], ci_stats[name]["vmax"] = lo, hi
+    if getattr(data, "time1", None) is not None:
+        ci_stats["time1"] = data.time1
+    if getattr(data, "ttb", None) is not None:
+        ci_stats["ttb"] = data.ttb
+    model.params = ci_stats
+
+    logger.info("- SNR and Chi2-test")
+    K, Q = model.K, model.Q
+    images, xy = data.images.cpu().double(), data.xy.cpu().double()
+    snr = torch.zeros(K, data.Nt, data.F, Q, dtype=torch.float64)
+    chi2 = torch.zeros(data.Nt, data.F, Q, dtype=torch.float64)
+    mean = lambda n: ci_stats[n]["Mean"].double()
+    for n in range(data.Nt):
+        snr[:, n], chi2[n] = snr_and_chi2(images[n], mean("height")[:, n], mean("width")[:, n], mean("x")[:, n],
+                                          mean("y")[:, n], xy[n], mean("background")[n], mean("gain"),
+                                          data.offset.mean, data.offset.var, data.P)
+    for q in range(Q):
+        sel = snr[..., q][ci_stats["theta_probs"][..., q] > 0.5]
+        summary.loc[f"SNR_{q}", "Mean"] = float(sel.mean()) if sel.numel() else float("nan")
+    cmax = float(quantile(chi2.flatten(), 0.99))
+    ci_stats["chi2"] = {"values": chi2.float(), "vmin": -0.03 * cmax, "vmax": 1.3 * cmax}
+
     if data.labels is not None:
         from sklearn.metrics import confusion_matrix, matthews_corrcoef, precision_score, recall_score
 
@@ -68,8 +132,15 @@ def save_stats(model, path, CI=0.95, save_matlab=False):
         tn, fp, fn, tp = confusion_matrix(true, pred, labels=(0, 1)).ravel()
         for k, v in (("TN", tn), ("FP", fp), ("FN", fn), ("TP", tp)):
             summary.loc[k, "Mean"] = v
-    pspec = ci_stats["p_specific"][data.is_ontarget.cpu()]
-    summary.loc["p(specific)", "Mean"] = float(pspec.mean()) if pspec.numel() else 0.0
+        # z_map at the truly specific AOI-frames: median and highest-density interval (stats.py:214-226)
+        zmap_on = (ci_stats["z_map"][on] > 0).long()
+        samples = torch.masked_select(zmap_on, torch.from_numpy(np.asarray(data.labels["z"])) > 0)
+        if samples.numel():
+            lo, hi = hpdi(samples, CI)
+            summary.loc["p(specific)", "Mean"] = float(quantile(samples, 0.5))
+            summary.loc["p(specific)", ll_col], summary.loc["p(specific)", ul_col] = float(lo), float(hi)
+        else:
+            summary.loc["p(specific)", "Mean"] = summary.loc["p(specific)", ll_col] = summary.loc["p(specific)", ul_col] = 0.0
     model.summary = summary
 
     if path is not None:

@@ -116,3 +116,28 @@ def test_fit_checkpoint_resume_and_stats_on_device(tmp_path):
     assert {"gain", "pi", "lamda", "proximity", "background", "height", "width", "x", "y", "m_probs", "z_probs",
             "theta_probs", "z_map", "p_specific"} <= set(p)  # cosmos.py:711-784
     assert float(p["gain"]["LL"]) < float(p["gain"]["Mean"]) < float(p["gain"]["UL"])
+
+
+def test_snr_chi2_quantile_hpdi():
+    """stats.py:29-86 on a noiseless image: chi2 = 0 and SNR = h sum(N^2) / sqrt(offset_var + b gain)."""
+    from tapqir_amd.distributions.util import gaussian_spots
+    from tapqir_amd.utils.stats import hpdi, quantile, snr_and_chi2
+
+    K, F, Q, P = 2, 3, 1, 14
+    h = torch.tensor([3000.0, 1500.0]).double().reshape(K, 1, 1).expand(K, F, Q)
+    w = torch.full((K, F, Q), 1.4).double()
+    x = torch.tensor([0.5, -3.0]).double().reshape(K, 1, 1).expand(K, F, Q)
+    y = torch.tensor([-0.5, 2.0]).double().reshape(K, 1, 1).expand(K, F, Q)
+    tl = torch.full((F, Q, 2), 6.5).double()
+    b = torch.full((F, Q), 150.0).double()
+    g = gaussian_spots(h, w, x, y, tl, P)
+    data = b[..., None, None] + g.sum(0) + 90.0
+    snr, chi2 = snr_and_chi2(data, h, w, x, y, tl, b, torch.tensor(7.0).double(), 90.0, 4.0, P)
+    assert chi2.abs().max() < 1e-20
+    wk = g / h[..., None, None]
+    expect = (g.sum(0)[None] * wk).sum((-1, -2)) / (4.0 + 150.0 * 7.0) ** 0.5
+    assert torch.allclose(snr, expect, rtol=1e-12)
+    s = torch.tensor([3.0, 1.0, 2.0, 10.0, 4.0])
+    assert float(quantile(s, 0.5)) == 3.0 and float(quantile(s, 0.25)) == 2.0
+    lo, hi = hpdi(torch.tensor([0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]), 0.8)
+    assert (float(lo), float(hi)) == (1.0, 1.0)
