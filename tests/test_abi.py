@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_the_c_header():
-    """ctypes mirrors of tq_ksmogn_args / tq_cosmos_args have the C compiler's layout."""
+    """ctypes mirrors of the argument structs have the C compiler's layout."""
     import subprocess
     import tempfile
 
@@ -42,9 +42,10 @@ def test_struct_sizes_match_the_c_header():
 #include <stddef.h>
 #include "tapqir_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(tq_ksmogn_args), offsetof(tq_ksmogn_args, m_kstride),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tq_ksmogn_args), offsetof(tq_ksmogn_args, m_kstride),
          offsetof(tq_ksmogn_args, scale), sizeof(tq_cosmos_args), offsetof(tq_cosmos_args, Nt),
-         offsetof(tq_cosmos_args, seed));
+         offsetof(tq_cosmos_args, seed), sizeof(tq_xtalk_args), offsetof(tq_xtalk_args, m_kstride),
+         offsetof(tq_xtalk_args, scale), sizeof(tq_probs_args));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -53,8 +54,9 @@ int main(void) {
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
-    K, Cs = _lib.KsmognArgs, _lib.CosmosArgs
-    want = [ctypes.sizeof(K), K.m_kstride.offset, K.scale.offset, ctypes.sizeof(Cs), Cs.Nt.offset, Cs.seed.offset]
+    K, Cs, X = _lib.KsmognArgs, _lib.CosmosArgs, _lib.XtalkArgs
+    want = [ctypes.sizeof(K), K.m_kstride.offset, K.scale.offset, ctypes.sizeof(Cs), Cs.Nt.offset, Cs.seed.offset,
+            ctypes.sizeof(X), X.m_kstride.offset, X.scale.offset, ctypes.sizeof(_lib.ProbsArgs)]
     assert got == want
 
 
