@@ -215,11 +215,13 @@ def main():
     allreduce = None
     if use_dist:
         def allreduce(t):
-            dist.all_reduce(t)
+            # left in flight: the engine overlaps it with the next step's local guide sampling (full-batch steps)
+            return dist.all_reduce(t, async_op=True)
 
     def run(n, ndx=None, fdx=None):
         for _ in range(n):
             eng.step(ndx, fdx, allreduce=allreduce)
+        eng.join()  # the last step's deferred global tail belongs to the timed region
 
     def barrier():
         if use_dist:

@@ -115,6 +115,7 @@ class CosmosEngine:
         self.gsum = self._gsum_buf[: self.n_gsum]  # the part that crosses ranks
         self.elbo_out = torch.zeros(1, dtype=torch.float64, device=dev)
         self._ws_key = None
+        self._pending = None  # (args, handle) of a step whose all-reduce is in flight
         self.adam_step = 0
         self.lr, self.betas, self.adam_eps = 0.005, (0.9, 0.999), 1e-8
         # contiguous batches at least this large use the lane-per-unit pixel kernel (64 units per wave):
@@ -130,6 +131,7 @@ class CosmosEngine:
         key = (nb, fb)
         if self._ws_key == key:
             return
+        self._finish_pending()
         K, M = self.K, 1 << self.K
         B = nb * fb * self.C
         dev, f32 = self.device, torch.float32
@@ -200,24 +202,52 @@ class CosmosEngine:
             _lib.check(getattr(self.lib, "tq_" + name)(C.byref(args), self._stream()), "tq_" + name)
 
     def step(self, ndx=None, fdx=None, allreduce=None):
-        """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``)."""
+        """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``).
+
+        ``allreduce(gsum)`` sums the cross-unit sums over the ranks of an AOI-sharded run.  If it returns a handle with
+        ``wait()`` (an asynchronous collective) and the step is a full-batch one, the global tail of the step (global
+        sites, Adam of the per-AOI and global parameters) is deferred: it runs after the NEXT step's local guide
+        sampling, which needs local parameters only, so the collective's latency hides behind that kernel.  ``join()``
+        (called by every read-out) completes a deferred tail."""
         a = self.make_args(ndx, fdx)
         a.fuse_adam = int(not a.zero_grad)  # full batch: Adam on the local block is fused into the unit kernel
         a.overlap_globals = int(self.overlap_globals and allreduce is None and not self._hostcheck)
         if allreduce is None and not self._hostcheck:
+            self._finish_pending()
             self.call("cosmos_step", a)
         else:
-            self.call("cosmos_sample_globals", a)
+            pending = self._pending
+            if pending is not None and not a.fuse_adam:
+                self._finish_pending()  # a minibatch step samples after the dense Adam of the previous one
+                pending = None
             self.call("cosmos_sample_locals", a)
+            if pending is not None:
+                self._finish_pending()
+            self.call("cosmos_sample_globals", a)
             self.call("cosmos_elbo_grads", a)
-            if allreduce is not None:
-                allreduce(self.gsum)
-            self.call("cosmos_globals_grad", a)
-            self.call("cosmos_adam", a)
+            handle = allreduce(self.gsum) if allreduce is not None else None
+            if handle is not None and hasattr(handle, "wait") and a.fuse_adam:
+                self._pending = (a, handle)
+            else:
+                if handle is not None and hasattr(handle, "wait"):
+                    handle.wait()
+                self.call("cosmos_globals_grad", a)
+                self.call("cosmos_adam", a)
         self.adam_step += 1
 
+    def _finish_pending(self):
+        """Global tail of a step whose all-reduce was left in flight."""
+        if self._pending is None:
+            return
+        a, handle = self._pending
+        self._pending = None
+        handle.wait()  # the current stream waits for the collective
+        self.call("cosmos_globals_grad", a)
+        self.call("cosmos_adam", a)
+
     def join(self):
-        """Make the current stream wait for the library's side stream (overlapped global work)."""
+        """Complete deferred work: a step's global tail waiting for its all-reduce, and the library's side stream."""
+        self._finish_pending()
         if not self._hostcheck:
             _lib.check(self.lib.tq_cosmos_join(self._stream()), "tq_cosmos_join")
 

@@ -38,11 +38,14 @@ def shard_dataset(data, rank, world):
     return sub, lo, data.images.shape[0]
 
 
-def make_allreduce(group=None):
-    """The single collective of a step: in-place sum of the cross-unit sums over all ranks."""
+def make_allreduce(group=None, async_op=False):
+    """The single collective of a step: in-place sum of the cross-unit sums over all ranks.  With ``async_op`` the
+    collective is left in flight and its handle returned: CosmosEngine.step then overlaps it with the next step's
+    local guide sampling (full-batch steps)."""
     import torch.distributed as dist
 
     def allreduce(gsum: torch.Tensor):
-        dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
+        return dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group, async_op=async_op) if async_op else \
+            dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
 
     return allreduce

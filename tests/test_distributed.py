@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, async_op=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -43,13 +43,16 @@ def _worker(rank, world, port, q):
             sv[n].copy_(fv[n][lo:hi])
         else:
             sv[n].copy_(fv[n])
-    allreduce = make_allreduce()
-    for _ in range(2):
+    allreduce = make_allreduce(async_op=async_op)
+    for _ in range(3 if async_op else 2):
         eng.step(allreduce=allreduce)
+    if async_op:
+        assert eng._pending is not None  # the last step's global tail is still waiting for its collective
+    eng.join()
     out = {"rank": rank, "lo": lo, "hi": hi, "elbo": float(eng.elbo_out[0]),
            "params": {n: v.clone().numpy() for n, v in eng.named("params").items()}}
     if rank == 0:
-        for _ in range(2):
+        for _ in range(3 if async_op else 2):
             full.step()
         out["full_elbo"] = float(full.elbo_out[0])
         out["full_params"] = {n: v.clone().numpy() for n, v in full.named("params").items()}
@@ -59,12 +62,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_steps_equal_single_process():
+@pytest.mark.parametrize("async_op", [False, True], ids=["blocking_allreduce", "overlapped_allreduce"])
+def test_two_rank_sharded_steps_equal_single_process(async_op):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() + 7 * int(async_op)) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, async_op)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o["rank"])
