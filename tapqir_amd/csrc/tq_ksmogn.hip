@@ -599,7 +599,7 @@ __device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 
 }
 
 template <int K, int P, bool BWD>
-__global__ __launch_bounds__(256, (K <= 2 ? 2 : 1)) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
+__global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
   static_assert(P % 2 == 0 && (P * P) % 4 == 0, "packed kernel needs an even tile side");
   constexpr int M = 1 << K;
   constexpr int R = ((P / 2) % 2) ? 2 : 1;  // rows per loop body so that the body starts on a float4 boundary
