@@ -7,18 +7,33 @@
 #include "tq_site.h"
 
 struct TqUnitIdx {
-  int n, f, c;
-  int64_t u;  // dataset unit index (n*F + f)*C + c
+  int n, c;
+  int64_t u;      // dataset unit index (n*F + f)*C + c
+  uint64_t elem;  // GLOBAL unit index (AOI sharding: n counted from the first AOI of rank 0): RNG stream id
 };
 
+// Minibatch position i -> dataset unit.  32-bit arithmetic (B < 2^31 is checked by the callers' hosts; a 64-bit
+// integer division costs ~100 VALU instructions per lane) and no division by the frame count for contiguous batches.
 TQ_HD TqUnitIdx tq_decode_unit(const tq_cosmos_args& a, int64_t i) {
   TqUnitIdx r;
-  r.c = (int)(i % a.C);
-  const int64_t ab = i / a.C;
-  const int bi = (int)(ab % a.fb), ai = (int)(ab / a.fb);
-  r.n = a.ndx ? a.ndx[ai] : ai;
-  r.f = a.fdx ? a.fdx[bi] : bi;
-  r.u = ((int64_t)r.n * a.F + r.f) * a.C + r.c;
+  const uint32_t iu = (uint32_t)i, C = (uint32_t)a.C;
+  uint32_t ab = iu, c = 0;
+  if (C > 1) {
+    ab = iu / C;
+    c = iu - ab * C;
+  }
+  r.c = (int)c;
+  if (a.ndx == nullptr && a.fdx == nullptr && a.fb == a.F) {  // contiguous in frames and AOIs: unit i IS dataset unit i
+    r.u = i;
+    r.n = (int)(ab / (uint32_t)a.F);
+  } else {
+    const uint32_t fb = (uint32_t)a.fb;
+    const uint32_t ai = ab / fb, bi = ab - ai * fb;
+    r.n = a.ndx ? a.ndx[ai] : (int)ai;
+    const int f = a.fdx ? a.fdx[bi] : (int)bi;
+    r.u = ((int64_t)r.n * a.F + f) * a.C + c;
+  }
+  r.elem = (uint64_t)r.u + (uint64_t)a.n_offset * (uint64_t)a.F * (uint64_t)a.C;
   return r;
 }
 
@@ -47,21 +62,19 @@ TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
   tq_globals_sample_site(s, p, C, a.seed, a.step, a.draw_globals, (TqGlobalBase*)a.gbase, (TqGlobals*)a.globals);
 }
 
-// ---- local guide sites: work item t = site * B + i, site in [0, 1+4K): b, h[k], w[k], x[k], y[k] ---------
+// ---- local guide sites: work item (site, i), site in [0, 1+4K): b, h[k], w[k], x[k], y[k]; row t = site * B + i ---
 // Draws the latent (or takes it from `lat` when draw_locals == 0) and evaluates the site's guide
 // terms (tq_site.h: TQ_NSITE_TERMS per site).  Lanes of a wave share the site kind (site-major
 // order), so the Gamma and Beta code paths do not diverge inside a wave.
-TQ_HD void tq_body_site(const tq_cosmos_args& a, int64_t t) {
+TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
   const int K = a.K;
   const int64_t B = tq_batch_units(a), U = tq_num_units(a);
   const int64_t NS = (int64_t)(1 + 4 * K) * B;
-  const int site = (int)(t / B);
-  const int64_t i = t % B;
+  const int64_t t = (int64_t)site * B + i;
   const TqUnitIdx ix = tq_decode_unit(a, i);
   const float* P = a.params;
-  const uint64_t elem = ((uint64_t)(ix.n + a.n_offset) * a.F + ix.f) * a.C + ix.c;
   TqPhilox s;
-  tq_philox_init(&s, a.seed, a.step, (uint32_t)site, elem);
+  tq_philox_init(&s, a.seed, a.step, (uint32_t)site, ix.elem);
   const float tiny = 1.17549435e-38f;
   float val = a.lat[t];
   float terms[TQ_NSITE_TERMS];
@@ -228,8 +241,11 @@ TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELB
   const float v = a.beta2 * a.exp_avg_sq[j] + (1.0f - a.beta2) * g * g;
   a.exp_avg[j] = m;
   a.exp_avg_sq[j] = v;
-  const float denom = sqrtf(v) / sqrtf(a.bias_correction2) + a.adam_eps;
-  a.params[j] = p - (a.lr / a.bias_correction1) * (m / denom);
+  // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps) with the 1-ulp hardware sqrt / rcp (the IEEE division and
+  // square-root sequences cost ~70 instructions per parameter; the update is accurate to ~1e-7 of lr either way)
+  const float rs2 = TQ_FRCP(TQ_FSQRT(a.bias_correction2));
+  const float lr1 = a.lr * TQ_FRCP(a.bias_correction1);
+  a.params[j] = p - lr1 * m * TQ_FRCP(TQ_FSQRT(v) * rs2 + a.adam_eps);
 }
 TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
   tq_adam_apply(a, j, a.params[j], a.grad[j]);
@@ -253,8 +269,8 @@ TQ_HD void tq_body_probs_globals(const tq_probs_args& a, int s, int particle) {
 template <int K>
 TQ_HD void tq_body_probs_unit(const tq_probs_args& a, int64_t u) {
   const int64_t U = (int64_t)a.Nt * a.F * a.C;
-  const int c = (int)(u % a.C);
-  const int n = (int)(u / ((int64_t)a.F * a.C));
+  const int c = (int)((uint32_t)u % (uint32_t)a.C);  // U < 2^31 (host-checked)
+  const int n = (int)((uint32_t)u / ((uint32_t)a.F * (uint32_t)a.C));
   float z1 = 0.0f, th[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) th[k] = 0.0f;

@@ -28,9 +28,10 @@ __global__ __launch_bounds__(64) void tq_sample_globals_kernel(const tq_cosmos_a
   if (threadIdx.x == 0) tq_body_sample_globals(a, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t total) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < total) tq_body_site(a, t);
+// grid.y = site: the site kind (Gamma / AffineBeta, which parameter rows) is uniform per workgroup
+__global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) tq_body_site(a, (int)blockIdx.y, i);
 }
 
 // ---- per-unit terms ------------------------------------------------------------------------------------
@@ -194,6 +195,10 @@ static int check_args(const tq_cosmos_args* a, const char* who) {
     tq_set_error("tq_cosmos_*: unsupported K/P/C or inconsistent batch geometry");
     return TQ_ERR_ARG;
   }
+  if (tq_num_units(*a) >= ((int64_t)1 << 31)) {
+    tq_set_error("tq_cosmos_*: Nt*F*C must be below 2^31 (unit indices are 32-bit on the device)");
+    return TQ_ERR_ARG;
+  }
   if (a->crosstalk && (a->C != 2 || a->K > 2)) {
     tq_set_error("tq_cosmos_*: the crosstalk model is implemented for Q = C = 2 and K <= 2");
     return TQ_ERR_ARG;
@@ -224,9 +229,9 @@ extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
     tq_set_error("tq_cosmos_sample_locals: lat or site is NULL");
     return TQ_ERR_ARG;
   }
-  const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
-  hipLaunchKernelGGL(tq_sample_locals_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, *a, total);
+  const int64_t B = tq_batch_units(*a);
+  hipLaunchKernelGGL(tq_sample_locals_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(1 + 4 * a->K)), dim3(256), 0,
+                     (hipStream_t)stream, *a, B);
   return check_launch("tq_sample_locals_kernel");
 }
 

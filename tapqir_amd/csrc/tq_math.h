@@ -41,12 +41,14 @@
 #define TQ_FRCP(x) __builtin_amdgcn_rcpf(x)
 #define TQ_FLOG2(x) __builtin_amdgcn_logf(x)
 #define TQ_FEXP2(x) __builtin_amdgcn_exp2f(x)
+#define TQ_FSQRT(x) __builtin_amdgcn_sqrtf(x)
 #else
 #define TQ_FLOG(x) logf(x)
 #define TQ_FEXP(x) expf(x)
 #define TQ_FRCP(x) (1.0f / (x))
 #define TQ_FLOG2(x) log2f(x)
 #define TQ_FEXP2(x) exp2f(x)
+#define TQ_FSQRT(x) sqrtf(x)
 #endif
 #define TQ_LOG2E 1.44269504088896340736f
 

@@ -272,8 +272,9 @@ void hc_cosmos_sample_globals(const tq_cosmos_args* a) {
   for (int s = 0; s < tq_num_gsites(*a); ++s) tq_body_sample_globals(*a, s);
 }
 void hc_cosmos_sample_locals(const tq_cosmos_args* a) {
-  const int64_t total = (int64_t)(1 + 4 * a->K) * tq_batch_units(*a);
-  for (int64_t t = 0; t < total; ++t) tq_body_site(*a, t);
+  const int64_t B = tq_batch_units(*a);
+  for (int site = 0; site < 1 + 4 * a->K; ++site)
+    for (int64_t i = 0; i < B; ++i) tq_body_site(*a, site, i);
 }
 
 }  // extern "C"
