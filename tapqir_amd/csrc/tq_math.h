@@ -188,7 +188,7 @@ TQ_HD float tq_sample_std_gamma(TqPhilox* s, float alpha) {
   float scale = 1.0f;
   if (alpha < 1.0f) {
     if (alpha == 0.0f) return 0.0f;
-    scale = powf(1.0f - tq_uniform(s), 1.0f / alpha);
+    scale = TQ_FEXP2(TQ_FLOG2(1.0f - tq_uniform(s)) * TQ_FRCP(alpha));  // u^(1/alpha) boost of Marsaglia-Tsang
     alpha += 1.0f;
     s->have = 0;  // the candidates below start on a fresh block
   }
@@ -304,6 +304,22 @@ TQ_HD_NOINLINE void tq_lgamma_digamma_d(double a, double* lg, double* dg) {
   *dg = lna - 0.5 * ra + dS - shift_d;
 }
 
+// digamma alone: shift to a >= 8 (sum of reciprocals), then the asymptotic series (next term 1/(240 a^8) <= 2.5e-10)
+TQ_HD double tq_digamma_fast_d(double a) {
+  double shift = 0.0;
+#pragma nounroll
+  for (int it = 0; it < 8 && a < 8.0; ++it) {
+    shift += tq_drcp(a);
+    a += 1.0;
+  }
+  const double ra = tq_drcp(a), r2 = ra * ra;
+  return tq_dlog(a) - 0.5 * ra - r2 * (1.0 / 12.0 - r2 * (1.0 / 120.0 - r2 * (1.0 / 252.0))) - shift;
+}
+
+// (1 - x)^e for 0 <= x < 1: the logarithm in fp64 (e can be thousands while x is tiny: e ln(1-x) must not inherit the
+// rounding of 1-x to fp32), the exponential of the O(1) product in fp32 (relative error ~1e-7)
+TQ_HD double tq_pow1m(double x, double e) { return (double)TQ_FEXP((float)(e * tq_dlog(1.0 - x))); }
+
 // ------------------------------------------------------------------------------------------
 // numerically safe logistic helpers (unconstrained -> constrained transforms)
 // ------------------------------------------------------------------------------------------
@@ -324,22 +340,24 @@ TQ_HD_NOINLINE float tq_std_gamma_grad(float alpha_, float x_) {
   // evaluated in double: the saddle-point branch cancels badly in float and this runs
   // once per latent scalar, not per pixel
   const double x = x_, alpha = alpha_;
-  if (x < 0.8) {  // Taylor series of the lower incomplete gamma function in x
-    double numer = 1.0, denom = alpha;
-    double series1 = numer / denom, series2 = numer / (denom * denom);
+  if (x < 0.8) {
+    // Taylor series of the lower incomplete gamma function in x.  With cdf = x^a s1, d cdf / d a = (ln x - psi(a)) cdf
+    // - x^a s2 and pdf = x^(a-1) e^-x (all three without the common 1/Gamma(a)) the powers of x cancel:
+    //   -(d cdf / d a) / pdf = x e^x [ s2 - (ln x - psi(a)) s1 ].
+    // The reciprocals 1/(a+i) of the series also shift psi(a) to psi(a+6).
+    double numer = 1.0, r = tq_drcp(alpha);
+    double series1 = r, series2 = r * r, shift = r;
+#pragma unroll
     for (int i = 1; i <= 5; ++i) {
-      numer *= -x / (double)i;
-      denom += 1.0;
-      series1 += numer / denom;
-      series2 += numer / (denom * denom);
+      numer *= -x * (1.0 / (double)i);
+      r = tq_drcp(alpha + (double)i);
+      series1 += numer * r;
+      series2 += numer * r * r;
+      shift += r;
     }
-    const double pow_x_alpha = pow(x, alpha);
-    const double gamma_pdf = pow(x, alpha - 1.0) * exp(-x);
-    const double gamma_cdf = pow_x_alpha * series1;
-    double lg, dg;
-    tq_lgamma_digamma_d(alpha, &lg, &dg);
-    const double gamma_cdf_alpha = (log(x) - dg) * gamma_cdf - pow_x_alpha * series2;
-    const double result = -gamma_cdf_alpha / gamma_pdf;
+    const double z = alpha + 6.0, rz = tq_drcp(z), rz2 = rz * rz;
+    const double psi = tq_dlog(z) - 0.5 * rz - rz2 * (1.0 / 12.0 - rz2 * (1.0 / 120.0 - rz2 * (1.0 / 252.0 - rz2 * (1.0 / 240.0)))) - shift;
+    const double result = x * (double)TQ_FEXP((float)x) * (series2 - (tq_dlog(x) - psi) * series1);
     return (result != result) ? 0.0f : (float)result;
   }
   if (alpha > 8.0) {  // Rice saddle-point expansion
@@ -364,19 +382,19 @@ TQ_HD_NOINLINE float tq_std_gamma_grad(float alpha_, float x_) {
     return (float)(-stirling * numer * tq_drcp(denom));
   }
   // bivariate rational approximation in (ln(x/alpha), ln alpha); coefficients: PyTorch (BSD-3)
-  const double v = tq_dlog(alpha);
-  const double u = tq_dlog(x) - v;
-  const double coef_uv[3][8] = {
-      {0.16009398, -0.094634809, 0.025146376, -0.0030648343, 1, 0.32668115, 0.10406089, 0.0014179084},
-      {0.53487893, 0.1298071, 0.065735949, -0.0015649758, 0.16639465, 0.020070113, -0.0035938915, -0.00058392623},
-      {0.040121004, -0.0065914022, -0.0026286047, -0.0013441777, 0.017050642, -0.0021309326, 0.00085092367,
-       -1.5247877e-07},
+  const float v = TQ_FLOG(alpha_);
+  const float u = TQ_FLOG(x_) - v;
+  const float coef_uv[3][8] = {
+      {0.16009398f, -0.094634809f, 0.025146376f, -0.0030648343f, 1.0f, 0.32668115f, 0.10406089f, 0.0014179084f},
+      {0.53487893f, 0.1298071f, 0.065735949f, -0.0015649758f, 0.16639465f, 0.020070113f, -0.0035938915f, -0.00058392623f},
+      {0.040121004f, -0.0065914022f, -0.0026286047f, -0.0013441777f, 0.017050642f, -0.0021309326f, 0.00085092367f,
+       -1.5247877e-07f},
   };
-  double coef_v[8];
+  float coef_v[8];
   for (int i = 0; i < 8; ++i) coef_v[i] = coef_uv[0][i] + u * (coef_uv[1][i] + u * coef_uv[2][i]);
-  const double p = coef_v[0] + v * (coef_v[1] + v * (coef_v[2] + v * coef_v[3]));
-  const double q = coef_v[4] + v * (coef_v[5] + v * (coef_v[6] + v * coef_v[7]));
-  return expf((float)(p * tq_drcp(q)));  // the result is a float: exp of a float-rounded argument is accurate to 1e-7
+  const float p = coef_v[0] + v * (coef_v[1] + v * (coef_v[2] + v * coef_v[3]));
+  const float q = coef_v[4] + v * (coef_v[5] + v * (coef_v[6] + v * coef_v[7]));
+  return TQ_FEXP(p * TQ_FRCP(q));  // fp32 throughout, as torch evaluates it for float32 tensors (O(1) quantities)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,31 +408,64 @@ TQ_HD double tq_digamma_d(double a) {
   return dg;
 }
 
+// fp32 digamma: shift to a >= 6 by the recurrence, then the asymptotic series (next term 1/(240 a^8) < 3e-9)
+TQ_HD float tq_digamma_f(float a) {
+  float shift = 0.0f;
+#pragma nounroll
+  for (int it = 0; it < 6 && a < 6.0f; ++it) {
+    shift += TQ_FRCP(a);
+    a += 1.0f;
+  }
+  const float ra = TQ_FRCP(a), r2 = ra * ra;
+  return TQ_FLOG(a) - 0.5f * ra - r2 * (1.0f / 12.0f - r2 * (1.0f / 120.0f - r2 * (1.0f / 252.0f))) - shift;
+}
+
+// The 1-x-small series regime of torch's _dirichlet_grad in fp32 (terms decay like (1-x)^i / i!; checked against
+// the fp64 evaluation to 5e-5).  The x-small regime stays in fp64: its alternating series cancels by factors of
+// several hundred when beta x is near the regime boundary and needs psi, ln x and 1/(alpha+i) to ~1e-9.
+TQ_HD float tq_beta_grad_beta_small_f(float x, float alpha, float beta) {
+  // psi(alpha + beta) - psi(beta) cancels when alpha << beta: the two digammas in fp64
+  const float factor = (float)(tq_digamma_fast_d((double)alpha + (double)beta) - tq_digamma_fast_d((double)beta));
+  float numer = 1.0f, betas = 1.0f, dbetas = 0.0f, series = factor * TQ_FRCP(alpha);
+#pragma nounroll
+  for (int i = 1; i <= 8; ++i) {
+    const float ci = (float)i;
+    numer *= -x * TQ_FRCP(ci);
+    dbetas = dbetas * (beta - ci) + betas;
+    betas = betas * (beta - ci);
+    series += numer * TQ_FRCP(alpha + ci) * (dbetas + factor * betas);
+  }
+  const float result = -TQ_FEXP((1.0f - beta) * log1pf(-x)) * series;  // -(1-x)^(1-beta) series
+  return (result != result) ? 0.0f : result;
+}
+
 TQ_HD double tq_beta_grad_alpha_small(double x, double alpha, double beta) {
-  const double factor = tq_digamma_d(alpha) - tq_digamma_d(alpha + beta) - log(x);
-  double numer = 1.0;
-  double series = numer / alpha * (factor + 1.0 / alpha);
+  const double factor = tq_digamma_fast_d(alpha) - tq_digamma_fast_d(alpha + beta) - tq_dlog(x);
+  double numer = 1.0, r = tq_drcp(alpha);
+  double series = numer * r * (factor + r);
+#pragma nounroll
   for (int i = 1; i <= 10; ++i) {
     const double ci = (double)i;
-    numer *= (ci - beta) * x / ci;
-    const double denom = alpha + ci;
-    series += numer / denom * (factor + 1.0 / denom);
+    numer *= (ci - beta) * x * tq_drcp(ci);
+    r = tq_drcp(alpha + ci);
+    series += numer * r * (factor + r);
   }
-  const double result = x * pow(1.0 - x, -beta) * series;
+  const double result = x * tq_pow1m(x, -beta) * series;
   return (result != result) ? 0.0 : result;
 }
 
 TQ_HD double tq_beta_grad_beta_small(double x, double alpha, double beta) {
-  const double factor = tq_digamma_d(alpha + beta) - tq_digamma_d(beta);
-  double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor / alpha;
+  const double factor = tq_digamma_fast_d(alpha + beta) - tq_digamma_fast_d(beta);
+  double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor * tq_drcp(alpha);
+#pragma nounroll
   for (int i = 1; i <= 8; ++i) {
     const double ci = (double)i;
-    numer *= -x / ci;
+    numer *= -x * tq_drcp(ci);
     dbetas = dbetas * (beta - ci) + betas;
     betas = betas * (beta - ci);
-    series += numer / (alpha + ci) * (dbetas + factor * betas);
+    series += numer * tq_drcp(alpha + ci) * (dbetas + factor * betas);
   }
-  const double result = -pow(1.0 - x, 1.0 - beta) * series;
+  const double result = -tq_pow1m(x, 1.0 - beta) * series;
   return (result != result) ? 0.0 : result;
 }
 
@@ -435,23 +486,22 @@ TQ_HD double tq_beta_grad_window(double x, double alpha, double beta) {
 
 TQ_HD double tq_beta_grad_alpha_mid(double x, double alpha, double beta) {
   const double total = alpha + beta;
-  const double mean = alpha / total;
-  const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+  const double rt = tq_drcp(total);
+  const double mean = alpha * rt;
+  const double sd = tq_dsqrt(alpha * beta * tq_drcp(total + 1.0)) * rt;
   if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) return tq_beta_grad_window(x, alpha, beta);
-  const double prefactor = -x / sqrt(2.0 * alpha * beta / total);
-  const double stirling = (1.0 + 1.0 / (12.0 * alpha) + 1.0 / (288.0 * alpha * alpha)) *
-                          (1.0 + 1.0 / (12.0 * beta) + 1.0 / (288.0 * beta * beta)) /
-                          (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
+  const double prefactor = -x * tq_drcp(tq_dsqrt(2.0 * alpha * beta * rt));
+  const double fa = tq_drcp(12.0 * alpha), fb = tq_drcp(12.0 * beta), ft = tq_drcp(12.0 * total);
+  const double stirling = (1.0 + fa + 0.5 * fa * fa) * (1.0 + fb + 0.5 * fb * fb) * tq_drcp(1.0 + ft + 0.5 * ft * ft);
   const double term1_num = 2.0 * (alpha * alpha) * (x - 1.0) + alpha * beta * (x - 1.0) - x * (beta * beta);
   const double axbx = alpha * (x - 1.0) + beta * x;
-  const double term1_den = sqrt(2.0 * alpha / beta) * (total * sqrt(total)) * axbx * axbx;
-  const double term1 = term1_num / term1_den;
-  const double term2 = 0.5 * log(alpha / (total * x));
-  const double term3_num = sqrt(8.0 * alpha * beta / total);
-  const double term3_den = beta * x + alpha * (x - 1.0);
-  const double term3 = term3_num / term3_den;
-  const double term4_base = beta * log(beta / (total * (1.0 - x))) + alpha * log(alpha / (total * x));
-  const double term4 = 1.0 / (term4_base * sqrt(term4_base));  // term4_base^(-3/2)
+  const double term1_den = tq_dsqrt(2.0 * alpha * tq_drcp(beta)) * (total * tq_dsqrt(total)) * axbx * axbx;
+  const double term1 = term1_num * tq_drcp(term1_den);
+  const double la = tq_dlog(alpha * rt * tq_drcp(x));
+  const double term2 = 0.5 * la;
+  const double term3 = tq_dsqrt(8.0 * alpha * beta * rt) * tq_drcp(axbx);
+  const double term4_base = beta * tq_dlog(beta * rt * tq_drcp(1.0 - x)) + alpha * la;
+  const double term4 = tq_drcp(term4_base * tq_dsqrt(term4_base));  // term4_base^(-3/2)
   const double term1234 = term1 + term2 * (term3 + (x < mean ? term4 : -term4));
   return stirling * prefactor * term1234;
 }
@@ -515,41 +565,42 @@ TQ_HD_NOINLINE float tq_dirichlet_grad(float x_, float alpha_, float total_) {
   const double beta = total - alpha;
   const double boundary = total * x * (1.0 - x);
   if (x <= 0.5 && boundary < 2.5) return (float)tq_beta_grad_alpha_small(x, alpha, beta);
-  if (x >= 0.5 && boundary < 0.75) return (float)(-tq_beta_grad_beta_small(1.0 - x, beta, alpha));
+  if (x >= 0.5 && boundary < 0.75) return -tq_beta_grad_beta_small_f(1.0f - x_, total_ - alpha_, alpha_);
   if (alpha > 6.0 && beta > 6.0) return (float)tq_beta_grad_alpha_mid(x, alpha, beta);
   // rational correction to an analytic approximation; coefficients: PyTorch (BSD-3)
-  const double c[2][3][3][4] = {
-      {{{1.003668233, -0.01061107488, -0.0657888334, 0.01201642863},
-        {0.6336835991, -0.3557432599, 0.05486251648, -0.001465281033},
-        {-0.03276231906, 0.004474107445, 0.002429354597, -0.0001557569013}},
-       {{0.221950385, -0.3187676331, 0.01799915743, 0.01074823814},
-        {-0.2951249643, 0.06219954479, 0.01535556598, 0.001550077057},
-        {0.02155310298, 0.004170831599, 0.001292462449, 6.976601077e-05}},
-       {{-0.05980841433, 0.008441916499, 0.01085618172, 0.002319392565},
-        {0.02911413504, 0.01400243777, -0.002721828457, 0.000751041181},
-        {0.005900514878, -0.001936558688, -9.495446725e-06, 5.385558597e-05}}},
-      {{{1, -0.02924021934, -0.04438342661, 0.007285809825},
-        {0.6357567472, -0.3473456711, 0.05454656494, -0.002407477521},
-        {-0.03301322327, 0.004845219414, 0.00231480583, -0.0002307248149}},
-       {{0.5925320577, -0.1757678135, 0.01505928619, 0.000564515273},
-        {0.1014815858, -0.06589186703, 0.01272886114, -0.0007316646956},
-        {-0.007258481865, 0.001096195486, 0.0003934994223, -4.12701925e-05}},
-       {{0.06469649321, -0.0236701437, 0.002902096474, -5.896963079e-05},
-        {0.001925008108, -0.002869809258, 0.0008000589141, -6.063713228e-05},
-        {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}},
+  const float c[2][3][3][4] = {
+      {{{1.003668233f, -0.01061107488f, -0.0657888334f, 0.01201642863f},
+        {0.6336835991f, -0.3557432599f, 0.05486251648f, -0.001465281033f},
+        {-0.03276231906f, 0.004474107445f, 0.002429354597f, -0.0001557569013f}},
+       {{0.221950385f, -0.3187676331f, 0.01799915743f, 0.01074823814f},
+        {-0.2951249643f, 0.06219954479f, 0.01535556598f, 0.001550077057f},
+        {0.02155310298f, 0.004170831599f, 0.001292462449f, 6.976601077e-05f}},
+       {{-0.05980841433f, 0.008441916499f, 0.01085618172f, 0.002319392565f},
+        {0.02911413504f, 0.01400243777f, -0.002721828457f, 0.000751041181f},
+        {0.005900514878f, -0.001936558688f, -9.495446725e-06f, 5.385558597e-05f}}},
+      {{{1.0f, -0.02924021934f, -0.04438342661f, 0.007285809825f},
+        {0.6357567472f, -0.3473456711f, 0.05454656494f, -0.002407477521f},
+        {-0.03301322327f, 0.004845219414f, 0.00231480583f, -0.0002307248149f}},
+       {{0.5925320577f, -0.1757678135f, 0.01505928619f, 0.000564515273f},
+        {0.1014815858f, -0.06589186703f, 0.01272886114f, -0.0007316646956f},
+        {-0.007258481865f, 0.001096195486f, 0.0003934994223f, -4.12701925e-05f}},
+       {{0.06469649321f, -0.0236701437f, 0.002902096474f, -5.896963079e-05f},
+        {0.001925008108f, -0.002869809258f, 0.0008000589141f, -6.063713228e-05f},
+        {-0.0003477407336f, 6.959756487e-05f, 1.097287507e-05f, -1.650964693e-06f}}},
   };
-  const double u = log(x);
-  const double a = log(alpha) - u;
-  const double b = log(total) - a;
-  const double pow_u[3] = {1.0, u, u * u};
-  const double pow_a[3] = {1.0, a, a * a};
-  double p = 0.0, q = 0.0;
+  // the O(1) rational correction in fp32 (as torch does for float32 tensors); the digamma difference below in fp64
+  const float u = TQ_FLOG(x_);
+  const float a = TQ_FLOG(alpha_) - u;
+  const float b = TQ_FLOG(total_) - a;
+  const float pow_u[3] = {1.0f, u, u * u};
+  const float pow_a[3] = {1.0f, a, a * a};
+  float p = 0.0f, q = 0.0f;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
-      const double ua = pow_u[i] * pow_a[j];
+      const float ua = pow_u[i] * pow_a[j];
       p += ua * (c[0][i][j][0] + b * (c[0][i][j][1] + b * (c[0][i][j][2] + b * c[0][i][j][3])));
       q += ua * (c[1][i][j][0] + b * (c[1][i][j][1] + b * (c[1][i][j][2] + b * c[1][i][j][3])));
     }
-  const double approx = x * (tq_digamma_d(total) - tq_digamma_d(alpha)) / beta;
-  return (float)(p / q * approx);
+  const double approx = x * (tq_digamma_fast_d(total) - tq_digamma_fast_d(alpha)) * tq_drcp(beta);
+  return p * TQ_FRCP(q) * (float)approx;
 }

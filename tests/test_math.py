@@ -57,7 +57,8 @@ def test_standard_gamma_grad_matches_torch():
 def test_dirichlet_grad_matches_torch():
     hc = load_hostcheck()
     g = torch.Generator().manual_seed(1)
-    n = 6000
+    torch.manual_seed(11)  # Beta(...).sample() below draws from the global generator
+    n = 60000
     c1 = 10 ** (torch.rand(n, generator=g) * 4.5 - 1.5)
     c0 = 10 ** (torch.rand(n, generator=g) * 4.5 - 1.5)
     x = torch.distributions.Beta(c1.double(), c0.double()).sample().clamp(1e-6, 1 - 1e-6)
@@ -113,6 +114,7 @@ def test_fused_beta_gradient_pair_matches_torch():
     """tq_beta_grad_pair_mid (both directions of one Beta draw at once) against torch._dirichlet_grad."""
     hc = load_hostcheck()
     g = torch.Generator().manual_seed(2)
+    torch.manual_seed(12)
     n = 20000
     c1 = 10 ** (torch.rand(n, generator=g) * 3.5 + 0.3)
     c0 = 10 ** (torch.rand(n, generator=g) * 3.5 + 0.3)
