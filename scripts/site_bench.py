@@ -22,9 +22,15 @@ eng.layout.set_constrained(eng.params, initial_values(eng, data))
 import time
 
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+state = sys.argv[2] if len(sys.argv) > 2 else None  # file with trained parameters: loaded if present, else written
+if state and os.path.exists(state):
+    eng.params.copy_(torch.load(state).to(dev))
+    nsteps = 0
 for _ in range(nsteps):
     eng.step()
 torch.cuda.synchronize()
+if state and not os.path.exists(state):
+    torch.save(eng.params.cpu(), state)
 t0 = time.perf_counter()
 for _ in range(50):
     eng.step()

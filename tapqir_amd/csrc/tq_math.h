@@ -440,15 +440,31 @@ TQ_HD float tq_beta_grad_beta_small_f(float x, float alpha, float beta) {
 }
 
 TQ_HD double tq_beta_grad_alpha_small(double x, double alpha, double beta) {
-  const double factor = tq_digamma_fast_d(alpha) - tq_digamma_fast_d(alpha + beta) - tq_dlog(x);
-  double numer = 1.0, r = tq_drcp(alpha);
-  double series = numer * r * (factor + r);
-#pragma nounroll
+  // 1/(alpha+i), i = 0..10, by batch inversion (one fp64 reciprocal of the running product, three multiplications per
+  // element); their sum also shifts psi(alpha) to psi(alpha + 11), where the asymptotic series is exact to 1e-12
+  double pref[11], r[11];
+  double prod = 1.0;
+#pragma unroll
+  for (int i = 0; i <= 10; ++i) {
+    pref[i] = prod;
+    prod *= alpha + (double)i;
+  }
+  double inv = tq_drcp(prod), shift = 0.0;
+#pragma unroll
+  for (int i = 10; i >= 0; --i) {
+    r[i] = inv * pref[i];
+    inv *= alpha + (double)i;
+    shift += r[i];
+  }
+  const double z = alpha + 11.0, rz = tq_drcp(z), rz2 = rz * rz;
+  const double psi_a = tq_dlog(z) - 0.5 * rz - rz2 * (1.0 / 12.0 - rz2 * (1.0 / 120.0 - rz2 * (1.0 / 252.0))) - shift;
+  const double factor = psi_a - tq_digamma_fast_d(alpha + beta) - tq_dlog(x);
+  double numer = 1.0;
+  double series = r[0] * (factor + r[0]);
+#pragma unroll
   for (int i = 1; i <= 10; ++i) {
-    const double ci = (double)i;
-    numer *= (ci - beta) * x * tq_drcp(ci);
-    r = tq_drcp(alpha + ci);
-    series += numer * r * (factor + r);
+    numer *= ((double)i - beta) * x * (1.0 / (double)i);
+    series += numer * r[i] * (factor + r[i]);
   }
   const double result = x * tq_pow1m(x, -beta) * series;
   return (result != result) ? 0.0 : result;
