@@ -181,9 +181,11 @@ __device__ __forceinline__ void tq_pixel_store(const tq_ksmogn_args& a, int64_t 
 #pragma unroll
   for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = bad ? -INFINITY : A.ll[mi];
   if (BWD) {
-    const float z = bad ? 0.0f : 1.0f;  // a unit with a pixel at or below the offset has log p = -inf: no gradient
+    // a unit with a pixel at or below every offset has log p = -inf for every combination: no gradient
+    // (selected, not multiplied: the sums of such a unit may hold inf / NaN)
+    const bool dead = bad || A.ll[0] == -INFINITY;
     // d alpha = d mu / g for every mu-parameter
-    a.g_background[i] = z * A.acc_b * rg;
+    a.g_background[i] = dead ? 0.0f : A.acc_b * rg;
     float acc_g = A.acc_g;
     if (ONE_OFFSET) {
       // sum_m W_m [alpha_m (da_m + 1) - v/g] = (1/g) [ sum_m W_m mu_m da_m + sum_m W_m mu_m - (sum_m W_m) v ]
@@ -201,17 +203,17 @@ __device__ __forceinline__ void tq_pixel_store(const tq_ksmogn_args& a, int64_t 
       }
       acc_g = rg * (mu_da + mu_w + Wsum * (b * fnpix - S_v));
     }
-    a.g_gain[i] = -z * acc_g * rg;
+    a.g_gain[i] = dead ? 0.0f : -acc_g * rg;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float rw = TQ_FRCP(wk[k]);
       const float S1x = A.Sx[k] - cx[k] * A.S0[k];
       const float S1y = A.Sy[k] - cy[k] * A.S0[k];
       const float S2 = A.Sr[k] - 2.0f * (cx[k] * A.Sx[k] + cy[k] * A.Sy[k]) + (cx[k] * cx[k] + cy[k] * cy[k]) * A.S0[k];
-      a.g_height[k * B + i] = z * A.S0[k] * rg * TQ_FRCP(hk[k]);
-      a.g_x[k * B + i] = z * rg * S1x * rw * rw;
-      a.g_y[k * B + i] = z * rg * S1y * rw * rw;
-      a.g_width[k * B + i] = z * rg * (S2 * rw * rw * rw - 2.0f * A.S0[k] * rw);
+      a.g_height[k * B + i] = dead ? 0.0f : A.S0[k] * rg * TQ_FRCP(hk[k]);
+      a.g_x[k * B + i] = dead ? 0.0f : rg * S1x * rw * rw;
+      a.g_y[k * B + i] = dead ? 0.0f : rg * S1y * rw * rw;
+      a.g_width[k * B + i] = dead ? 0.0f : rg * (S2 * rw * rw * rw - 2.0f * A.S0[k] * rw);
     }
   }
 }

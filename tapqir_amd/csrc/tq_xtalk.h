@@ -225,10 +225,13 @@ TQ_HD void tq_xtalk_finish(const tq_xtalk_args& a, int64_t g, const TqXtGroup<K>
     }
   }
   if (BWD) {
+    // an AOI-frame with a pixel at or below every offset has log p = -inf for every combination: no gradient
+    // (selected, not multiplied: the sums of such an AOI-frame may hold inf / NaN)
+    const bool dead = A.ll[0] == -INFINITY;
 #pragma unroll
     for (int c = 0; c < Q; ++c) {
-      a.g_background[g * Q + c] = A.acc_b[c] * rg;
-      a.g_gain[g * Q + c] = c == 0 ? -A.acc_g * rg : 0.0f;
+      a.g_background[g * Q + c] = dead ? 0.0f : A.acc_b[c] * rg;
+      a.g_gain[g * Q + c] = (c == 0 && !dead) ? -A.acc_g * rg : 0.0f;
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -238,17 +241,17 @@ TQ_HD void tq_xtalk_finish(const tq_xtalk_args& a, int64_t g, const TqXtGroup<K>
         const int64_t i = (int64_t)k * B + g * Q + q;
         const float rw = TQ_FRCP(G.w[s]);
         const float s0 = A.S0[s][0] + A.S0[s][1];
-        a.g_height[i] = s0 * rg * TQ_FRCP(G.h[s]);
-        a.g_x[i] = rg * A.S1x[s] * rw * rw;
-        a.g_y[i] = rg * A.S1y[s] * rw * rw;
-        a.g_width[i] = rg * (A.S2[s] * rw * rw * rw - 2.0f * s0 * rw);
+        a.g_height[i] = dead ? 0.0f : s0 * rg * TQ_FRCP(G.h[s]);
+        a.g_x[i] = dead ? 0.0f : rg * A.S1x[s] * rw * rw;
+        a.g_y[i] = dead ? 0.0f : rg * A.S1y[s] * rw * rw;
+        a.g_width[i] = dead ? 0.0f : rg * (A.S2[s] * rw * rw * rw - 2.0f * s0 * rw);
       }
 #pragma unroll
       for (int c = 0; c < Q; ++c) {
         float sa = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) sa += A.S0[q * K + k][c];
-        if (a.g_alpha) a.g_alpha[(int64_t)q * B + g * Q + c] = rg * sa * TQ_FRCP(G.alpha[q][c]);
+        if (a.g_alpha) a.g_alpha[(int64_t)q * B + g * Q + c] = dead ? 0.0f : rg * sa * TQ_FRCP(G.alpha[q][c]);
       }
     }
   }

@@ -177,7 +177,7 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
     }
     for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = bad ? -INFINITY : (float)ll[mi];
     if (bwd) {
-      const double z = bad ? 0.0 : 1.0;
+      const double z = (bad || ll[0] == -INFINITY) ? 0.0 : 1.0;
       a.g_background[i] = (float)(z * acc_b * rg);
       if (one) {
         double Wsum = 0, mu_da = b * acc_b, mu_w = 0;
