@@ -103,6 +103,7 @@ class cosmos(Model):
     # -- engine / parameters -------------------------------------------------------------------------
     def _make_engine(self, **kw):
         if self.engine is None:
+            kw = {**getattr(self, "_engine_kwargs", {}), **kw}  # AOI sharding: tapqir_amd.parallel.attach
             self.engine = CosmosEngine(self.data, K=self.K, priors=self.priors, device=self.device, **kw)
         return self.engine
 

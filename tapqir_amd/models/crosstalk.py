@@ -51,7 +51,8 @@ class crosstalk(cosmos):
 
     def _make_engine(self, **kw):
         if self.engine is None:
-            self.engine = CosmosEngine(self.data, K=self.K, priors=self.priors, device=self.device, crosstalk=True, **kw)
+            self.engine = CosmosEngine(self.data, K=self.K, priors=self.priors, device=self.device, crosstalk=True,
+                                       **{**getattr(self, "_engine_kwargs", {}), **kw})
         return self.engine
 
     def init_parameters(self):

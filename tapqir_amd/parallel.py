@@ -49,3 +49,21 @@ def make_allreduce(group=None, async_op=False):
             dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
 
     return allreduce
+
+
+def attach(model, group=None, async_op=True):
+    """Turn a loaded (``model.load``) but not yet initialised model into one rank of an AOI-sharded fit: keep this
+    rank's AOIs, key the RNG streams and plate scales by the global AOI indices, install the step's all-reduce, and give
+    every rank its own checkpoint directory.  Call between ``model.load(path)`` and ``model.init(...)`` with
+    ``torch.distributed`` initialised (backend "nccl" = RCCL on the GPUs; "gloo" works for rehearsals)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sub, lo, Nt_global = shard_dataset(model.data, rank, world)
+    model.data = sub
+    model.engine = None
+    model._engine_kwargs = dict(n_offset=lo, Nt_global=Nt_global)
+    model.allreduce = make_allreduce(group, async_op=async_op)
+    if world > 1 and model.run_path is not None:
+        model.run_path = model.run_path / f"rank{rank}"
+    return model

@@ -141,3 +141,38 @@ def test_snr_chi2_quantile_hpdi():
     assert float(quantile(s, 0.5)) == 3.0 and float(quantile(s, 0.25)) == 2.0
     lo, hi = hpdi(torch.tensor([0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]), 0.8)
     assert (float(lo), float(hi)) == (1.0, 1.0)
+
+
+@pytest.mark.gpu
+def test_parallel_attach_single_rank_group(tmp_path):
+    """tapqir_amd.parallel.attach on a one-rank RCCL group: the sharded code path (staged step, asynchronous all-reduce,
+    deferred global tail) gives the same parameters as the plain single-process fit."""
+    import os
+
+    import torch.distributed as dist
+
+    from tapqir_amd.models import models
+    from tapqir_amd.parallel import attach
+    from tapqir_amd.utils.dataset import save
+    from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+    save(simulate(2, 4, 8, 1, 14, seed=1, params=TEST_PARAMS), tmp_path)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for sharded in (False, True):
+            m = models["cosmos"](S=1, K=2, device="cuda", dtype="float")
+            m.load(tmp_path)
+            if sharded:
+                attach(m)
+            m.init(lr=0.005, nbatch_size=4, fbatch_size=8)
+            m.run(5, progress_bar=lambda x: x)
+            assert torch.isfinite(m.engine.params).all()
+            outs.append((m.engine.params.clone(), m.iter_loss))
+            (tmp_path / ".tapqir" / "cosmos_model.tpqr").unlink()
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+        assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
+    finally:
+        dist.destroy_process_group()
