@@ -173,6 +173,7 @@ IL_CASES = [  # contiguous batches through the lane-per-unit kernel on the inter
     ("K2_P20", dict(N=2, F=2, P=20), 2),
     ("K3_P20", dict(N=2, F=2, P=20), 3),           # the c5 shape: packed kernel, row-at-a-time bodies
     ("K3_P14", dict(N=2, F=3), 3),
+    ("K4_P14", dict(N=2, F=2), 4),
     ("K2_masked_aoi", dict(N=4, F=3, mask=torch.tensor([True, False, True, True])), 2),
 ]
 

@@ -16,6 +16,7 @@ CASES = [
     ("K2_minibatch", dict(N=4, F=6), 2, [0, 2, 3], [1, 4, 5, 0]),
     ("K1_minibatch", dict(N=4, F=5), 1, [3, 0], [0, 2, 4]),
     ("K3_P9", dict(N=2, F=3, P=9), 3, [1, 0], [2, 0, 1]),
+    ("K4_max_spots", dict(N=2, F=2), 4, None, None),  # TQ_MAX_K: 16 spot-presence combinations
     ("K2_fullbatch", dict(N=4, F=3), 2, None, None),
     ("K2_two_channels", dict(N=4, F=3, C=2), 2, [0, 3], [0, 2]),
     ("K2_offset_histogram", dict(N=2, F=3, offsets="hist"), 2, None, None),
