@@ -232,7 +232,7 @@ def main():
     # The first ~1000 kernel launches of a process end with ONE host-side stall of ~80 ms inside the
     # HIP runtime (measured: scripts/diag_hiccup.py; the GPU is idle meanwhile, no kernel of ours is
     # involved).  Push the process past that point before the warm-up/timed steps the driver asks for.
-    run(150)
+    run(400)  # >= 1500 launches with 4 launches per pipelined step
     barrier()
 
     # ---- headline: full-batch steps -----------------------------------------------------------------

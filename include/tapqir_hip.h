@@ -230,11 +230,6 @@ typedef struct {
   int32_t fuse_adam;           /* 1 (full batch only): tq_cosmos_elbo_grads applies Adam to the local parameters of
                                   each unit right where their gradient is formed (no gradient round trip through
                                   HBM) and tq_cosmos_adam then updates only the per-AOI and global tail */
-  int32_t overlap_globals;     /* tq_cosmos_step with fuse_adam: run the single-workgroup global work (cross-unit sums,
-                                  global sites, Adam of the per-AOI/global tail, next step's global draws) on a side
-                                  HIP stream of the library, concurrently with the next step's local guide sampling.
-                                  Results (elbo_out, global parameters) are then complete on `stream` only after
-                                  tq_cosmos_join(stream) or a device synchronisation */
   int32_t crosstalk;           /* 1: the crosstalk model (tapqir/models/crosstalk.py; Q = C = 2, K <= 2): one data site per
                                   AOI-frame whose channel c sees every dye's spots scaled by alpha[q][c]; the global block
                                   of the parameter buffer grows by alpha_mean[Q][2], alpha_size[Q] (4+8Q entries), gsum
@@ -265,8 +260,15 @@ int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream);
 int tq_cosmos_adam(const tq_cosmos_args* a, void* stream);
 /* all of the above back to back */
 int tq_cosmos_step(const tq_cosmos_args* a, void* stream);
-/* make `stream` wait for the library's side stream (see overlap_globals) */
-int tq_cosmos_join(void* stream);
+/* Full-batch pipeline (fuse_adam steps).  The single-workgroup TAIL of a step -- cross-unit sums, global sites, total
+ * ELBO, Adam of the per-AOI and global parameters (~35 us of latency on one CU) -- does not have to finish before the
+ * NEXT step samples its local guide sites (they read local parameters only, already updated by the fused Adam).
+ * tq_cosmos_step_overlapped(a, prev) runs [local sampling of a + tail of prev + global draws of a] in ONE launch (the
+ * tail occupies one extra workgroup of the ~14 000), then the likelihood, per-unit and per-AOI kernels of `a`, and
+ * leaves the tail of `a` pending: pass `a` as `prev` of the next call, or finish it with tq_cosmos_tail(a) before
+ * reading elbo_out / the per-AOI and global parameters.  prev == NULL: nothing pending (first step). */
+int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
+int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------

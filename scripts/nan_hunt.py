@@ -38,6 +38,7 @@ for it in range(args.iters):
     prev = eng.params.clone()
     ndx, fdx = m._subsample()
     eng.step(ndx, fdx)
+    eng.join()
     torch.cuda.synchronize()
     elbo = float(eng.elbo_out[0])
     ok = torch.isfinite(eng.params).all().item() and elbo == elbo and abs(elbo) != float("inf")

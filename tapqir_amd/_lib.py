@@ -60,7 +60,7 @@ class CosmosArgs(C.Structure):
         ("gain_std", C.c_float), ("lamda_rate", C.c_float), ("proximity_rate", C.c_float),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("bias_correction1", C.c_float), ("bias_correction2", C.c_float),
-        ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32), ("overlap_globals", C.c_int32), ("crosstalk", C.c_int32),
+        ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32), ("crosstalk", C.c_int32),
         ("seed", C.c_uint64), ("step", C.c_uint32),
     ]
 
@@ -102,7 +102,8 @@ EXPORTS = [
     "tq_interleaved_floats", "tq_interleaved_floats_n", "tq_images_interleave_n", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_join", "tq_cosmos_probs",
+    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail",
+    "tq_cosmos_probs",
 ]
 
 _lib = None
@@ -147,12 +148,12 @@ def load():
     lib.tq_ksmogn_log_prob.argtypes = [C.POINTER(KsmognArgs), C.c_void_p]
     lib.tq_ksmogn_log_prob.restype = C.c_int
     for name in ("tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step"):
+                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_tail"):
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int
-    lib.tq_cosmos_join.argtypes = [C.c_void_p]
-    lib.tq_cosmos_join.restype = C.c_int
+    lib.tq_cosmos_step_overlapped.argtypes = [C.POINTER(CosmosArgs), C.POINTER(CosmosArgs), C.c_void_p]
+    lib.tq_cosmos_step_overlapped.restype = C.c_int
     lib.tq_cosmos_probs.argtypes = [C.POINTER(ProbsArgs), C.c_void_p]
     lib.tq_cosmos_probs.restype = C.c_int
     _lib = lib

@@ -135,9 +135,9 @@ __device__ __forceinline__ double tq_wave_sum_d(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
-  __shared__ double s_w[4][TQ_MAX_NGSUM];
-  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+// body for ONE workgroup of 256 threads; s_w / s_e are its shared scratch
+__device__ __forceinline__ void tq_reduce_globals_body(const tq_cosmos_args& a, const int64_t nblk, const int64_t B,
+                                                       double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
   const int nq = tq_num_gsum(a);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // every thread walks the rows once, carrying all columns (nq <= 15); then shuffle + 4-way LDS sum
@@ -171,6 +171,41 @@ __global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_
     for (int j = 0; j < ns; ++j) eg += s_e[j];
     a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
   }
+}
+
+__global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
+  __shared__ double s_w[4][TQ_MAX_NGSUM];
+  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+  tq_reduce_globals_body(a, nblk, B, s_w, s_e);
+}
+
+// Full-batch pipeline (tq_cosmos_step_overlapped): the local guide sampling of step t, with ONE extra workgroup (block (0, 0),
+// dispatched first) that runs the single-workgroup tail of step t-1 -- cross-unit sums, global sites, total ELBO, Adam
+// of the per-AOI / global parameters -- and then draws the global sites of step t from the updated parameters.  The
+// sampling of the local sites reads local parameters only (already updated by the Adam fused into the unit kernel of
+// step t-1), so the ~35 us latency chain of the tail hides behind the ~14 000 sampling workgroups of the same launch.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tq_sample_locals_tail_kernel(
+    const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B) {
+  if (blockIdx.y == 0) {
+    if (blockIdx.x != 0) return;
+    __shared__ double s_w[4][TQ_MAX_NGSUM];
+    __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+    if (has_prev) {
+      const int64_t Bp = tq_batch_units(prev);
+      tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
+      __syncthreads();
+      const int64_t total = tq_num_params(prev);
+      for (int64_t j = tq_aoi_base(prev) + threadIdx.x; j < total; j += 256) tq_body_adam(prev, j);
+      __threadfence();
+      __syncthreads();
+    }
+    const int ns = tq_num_gsites(a);
+    if ((threadIdx.x & 63) == 0)
+      for (int s = threadIdx.x >> 6; s < ns; s += 4) tq_body_sample_globals(a, s);
+    return;
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) tq_body_site(a, (int)blockIdx.y - 1, i);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -347,33 +382,7 @@ extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {
   return check_launch("tq_adam_kernel");
 }
 
-// ---- side stream for the single-workgroup global work (overlap_globals) -----------------------------------
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_start = nullptr, g_ev_globals = nullptr, g_ev_local = nullptr, g_ev_side_done = nullptr;
-static bool g_side_used = false;
-
-static int side_init() {
-  if (g_side) return TQ_OK;
-  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&g_ev_start, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g_ev_globals, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g_ev_local, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g_ev_side_done, hipEventDisableTiming) != hipSuccess) {
-    tq_set_error("tq_cosmos_step: cannot create the side stream / events");
-    g_side = nullptr;
-    return TQ_ERR_LAUNCH;
-  }
-  return TQ_OK;
-}
-
-extern "C" int tq_cosmos_join(void* stream) {
-  if (g_side && g_side_used && hipStreamWaitEvent((hipStream_t)stream, g_ev_side_done, 0) != hipSuccess) {
-    tq_set_error("tq_cosmos_join: hipStreamWaitEvent failed");
-    return TQ_ERR_LAUNCH;
-  }
-  return TQ_OK;
-}
-
+// ---- whole steps ---------------------------------------------------------------------------------------------
 static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
   if (!a->grad || !a->gsum || !a->elbo_out) {
     tq_set_error("tq_cosmos_step: NULL required pointer");
@@ -385,42 +394,39 @@ static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
   return check_launch("tq_reduce_globals_kernel");
 }
 
+extern "C" int tq_cosmos_tail(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "tail")) return rc;
+  if (int rc = launch_reduce_globals(a, (hipStream_t)stream)) return rc;
+  return tq_cosmos_adam(a, stream);
+}
+
 extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "step")) return rc;
-  hipStream_t main = (hipStream_t)stream;
-  if (!(a->overlap_globals && a->fuse_adam)) {
-    // serial: everything on the caller's stream (after any earlier overlapped step has drained)
-    if (int rc = tq_cosmos_join(stream)) return rc;
-    if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
-    if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
-    if (int rc = elbo_grads_impl(a, stream, false)) return rc;
-    if (int rc = launch_reduce_globals(a, main)) return rc;
-    return tq_cosmos_adam(a, stream);
-  }
-  // Overlapped (full batch, local Adam fused into the unit kernel).  The chain
-  //     cross-unit sums -> global sites -> Adam of the per-AOI/global tail -> next step's global draws
-  // is a few single-workgroup launches (~50 us of one CU); it runs on the side stream while the main
-  // stream already samples the NEXT step's local guide sites (which read local parameters only):
-  //   side: [wait start] sample_globals(t) ............................ [wait local(t)] sums+globals(t), tail Adam(t)
-  //   main: site(t) [wait globals(t)] pixel(t) unit(t) aoi(t) [local(t)] ... next call: site(t+1)
-  if (int rc = side_init()) return rc;
-  g_side_used = true;
-  // whatever the host queued on `stream` before this call (parameter loads, the previous step) comes first
-  if (hipEventRecord(g_ev_start, main) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_start, 0) != hipSuccess) {
-    tq_set_error("tq_cosmos_step: event record/wait failed");
-    return TQ_ERR_LAUNCH;
-  }
-  if (int rc = tq_cosmos_sample_globals(a, (void*)g_side)) return rc;
-  hipEventRecord(g_ev_globals, g_side);
+  if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
   if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
-  hipStreamWaitEvent(main, g_ev_globals, 0);
   if (int rc = elbo_grads_impl(a, stream, false)) return rc;
-  hipEventRecord(g_ev_local, main);
-  hipStreamWaitEvent(g_side, g_ev_local, 0);
-  if (int rc = launch_reduce_globals(a, g_side)) return rc;
-  if (int rc = tq_cosmos_adam(a, (void*)g_side)) return rc;
-  hipEventRecord(g_ev_side_done, g_side);
-  return TQ_OK;
+  return tq_cosmos_tail(a, stream);
+}
+
+extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream) {
+  if (int rc = check_args(a, "step_overlapped")) return rc;
+  if (prev)
+    if (int rc = check_args(prev, "step_overlapped (prev)")) return rc;
+  if (!a->fuse_adam || (prev && !prev->fuse_adam)) {
+    tq_set_error("tq_cosmos_step_overlapped: full-batch steps with fuse_adam only (the next step's local sampling must not depend on the pending tail)");
+    return TQ_ERR_ARG;
+  }
+  if (!a->lat || !a->site || !a->grad || !a->gsum || !a->elbo_out || !a->exp_avg || !a->exp_avg_sq ||
+      (prev && (!prev->grad || !prev->gsum || !prev->elbo_out || !prev->exp_avg || !prev->exp_avg_sq || !prev->blk_part ||
+                !prev->aoi_part))) {
+    tq_set_error("tq_cosmos_step_overlapped: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  const int64_t B = tq_batch_units(*a);
+  hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(2 + 4 * a->K)), dim3(256), 0,
+                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? 1 : 0, B);
+  if (int rc = check_launch("tq_sample_locals_tail_kernel")) return rc;
+  return elbo_grads_impl(a, stream, false);
 }
 
 // ---- posterior read-out (cosmos.compute_probs) -------------------------------------------------------------

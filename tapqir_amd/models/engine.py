@@ -121,17 +121,17 @@ class CosmosEngine:
         # contiguous batches at least this large use the lane-per-unit pixel kernel (64 units per wave):
         # 65536 units = one wave per SIMD of an MI355X
         self.il_min_units = 65536
-        # full-batch steps can run the single-workgroup global work on the library's side stream (see
-        # include/tapqir_hip.h: overlap_globals).  Measured on MI355X at the c2 size the ~50 us it hides are
-        # given back by the two cross-queue event waits per step (~10 us each), so it is opt-in.
-        self.overlap_globals = os.environ.get("TAPQIR_AMD_OVERLAP", "0") == "1"
+        # full-batch single-GPU steps leave their single-workgroup tail pending and run it inside the next step's
+        # sampling launch (include/tapqir_hip.h: tq_cosmos_step_overlapped); TAPQIR_AMD_OVERLAP=0 turns it off
+        self.overlap_tail = os.environ.get("TAPQIR_AMD_OVERLAP", "1") != "0"
+        self._tail_args = None  # arguments of the step whose tail is pending
 
     # -- workspace ---------------------------------------------------------------------------------
     def _workspace(self, nb, fb):
         key = (nb, fb)
         if self._ws_key == key:
             return
-        self._finish_pending()
+        self.join()
         K, M = self.K, 1 << self.K
         B = nb * fb * self.C
         dev, f32 = self.device, torch.float32
@@ -211,11 +211,18 @@ class CosmosEngine:
         (called by every read-out) completes a deferred tail."""
         a = self.make_args(ndx, fdx)
         a.fuse_adam = int(not a.zero_grad)  # full batch: Adam on the local block is fused into the unit kernel
-        a.overlap_globals = int(self.overlap_globals and allreduce is None and not self._hostcheck)
         if allreduce is None and not self._hostcheck:
             self._finish_pending()
-            self.call("cosmos_step", a)
+            if self.overlap_tail and a.fuse_adam:
+                prev = self._tail_args
+                _lib.check(self.lib.tq_cosmos_step_overlapped(C.byref(a), None if prev is None else C.byref(prev),
+                                                              self._stream()), "tq_cosmos_step_overlapped")
+                self._tail_args = a
+            else:
+                self._finish_tail()
+                self.call("cosmos_step", a)
         else:
+            self._finish_tail()
             pending = self._pending
             if pending is not None and not a.fuse_adam:
                 self._finish_pending()  # a minibatch step samples after the dense Adam of the previous one
@@ -245,11 +252,17 @@ class CosmosEngine:
         self.call("cosmos_globals_grad", a)
         self.call("cosmos_adam", a)
 
+    def _finish_tail(self):
+        """Tail of a pipelined full-batch step (tq_cosmos_step_overlapped left it pending)."""
+        if self._tail_args is not None:
+            a, self._tail_args = self._tail_args, None
+            self.call("cosmos_tail", a)
+
     def join(self):
-        """Complete deferred work: a step's global tail waiting for its all-reduce, and the library's side stream."""
+        """Complete deferred work: the pending tail of a pipelined step, or the global tail of a sharded step that waits
+        for its all-reduce.  Every read-out of elbo_out / parameters goes through here."""
         self._finish_pending()
-        if not self._hostcheck:
-            _lib.check(self.lib.tq_cosmos_join(self._stream()), "tq_cosmos_join")
+        self._finish_tail()
 
     # -- named views -----------------------------------------------------------------------------------
     def named(self, which="params"):

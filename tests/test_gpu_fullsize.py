@@ -111,7 +111,9 @@ def test_steps_improve_the_elbo_and_stay_finite(data):
     for it in range(30):
         eng.step()
         if it % 10 == 9 or it == 0:
+            eng.join()  # the step's global tail (ELBO, global parameters) is pending until the next launch
             torch.cuda.synchronize()
             elbos.append(float(eng.elbo_out[0]))
+    eng.join()
     assert torch.isfinite(eng.params).all() and torch.isfinite(eng.exp_avg_sq).all()
     assert elbos[-1] > elbos[0], elbos

@@ -145,6 +145,7 @@ def test_full_step_trajectory(minibatch):
         nd = torch.randperm(N, generator=g)[:3] if minibatch else torch.arange(N)
         fd = torch.randperm(F, generator=g)[:4] if minibatch else torch.arange(F)
         eng.step(nd if minibatch else None, fd if minibatch else None)
+        eng.join()  # full-batch steps leave their global tail pending for the next launch
         torch.cuda.synchronize()
         lat32 = read_engine_latents(eng, len(nd), len(fd))
         with torch.no_grad():
