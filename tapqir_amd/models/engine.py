@@ -266,5 +266,5 @@ class CosmosEngine:
 
     # -- named views -----------------------------------------------------------------------------------
     def named(self, which="params"):
-        self.join()  # reads that follow on the current stream see the side stream's updates
+        self.join()  # finish a pending global tail first: the views then hold the parameters after the last step
         return self.layout.views(getattr(self, which))
