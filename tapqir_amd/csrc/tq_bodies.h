@@ -117,6 +117,7 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
 }
 
 TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO);
+TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, float dELBO, float m_old, float v_old);
 
 // ---- per-unit ELBO terms and gradients --------------------------------------------------------------------
 // part[] receives this unit's contribution to the cross-unit sums (layout TQ_GS_*).
@@ -178,12 +179,23 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
   in.on = a.is_ontarget[ix.n] ? 1 : 0;
   in.q = ix.c;
 
+  // the Adam moments of the fused update are requested before the arithmetic below so that they arrive during it
+  float m_old[NL], v_old[NL];
+  if (a.fuse_adam) {
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+      m_old[r] = a.exp_avg[(int64_t)r * U + ix.u];
+      v_old[r] = a.exp_avg_sq[(int64_t)r * U + ix.u];
+    }
+  }
+
   TqUnitOut<K> out;
   tq_cosmos_unit<K>(in, G, C, &out);
 
   if (a.fuse_adam) {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) tq_adam_apply(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r]);
+    for (int r = 0; r < NL; ++r)
+      tq_adam_apply_given(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r], m_old[r], v_old[r]);
   } else {
 #pragma unroll
     for (int r = 0; r < NL; ++r) a.grad[(int64_t)r * U + ix.u] = masked ? 0.0f : out.g[r];
@@ -236,9 +248,12 @@ TQ_HD double tq_body_globals_grad(const tq_cosmos_args& a, int s) {
 // ---- Adam on one element (torch.optim.Adam, no amsgrad / weight decay; minimises -ELBO) ------------------
 // p = current parameter value, dELBO = d ELBO / d param
 TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO) {
+  tq_adam_apply_given(a, j, p, dELBO, a.exp_avg[j], a.exp_avg_sq[j]);
+}
+TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, float dELBO, float m_old, float v_old) {
   const float g = -dELBO;
-  const float m = a.beta1 * a.exp_avg[j] + (1.0f - a.beta1) * g;
-  const float v = a.beta2 * a.exp_avg_sq[j] + (1.0f - a.beta2) * g * g;
+  const float m = a.beta1 * m_old + (1.0f - a.beta1) * g;
+  const float v = a.beta2 * v_old + (1.0f - a.beta2) * g * g;
   a.exp_avg[j] = m;
   a.exp_avg_sq[j] = v;
   // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps) with the 1-ulp hardware sqrt / rcp (the IEEE division and
