@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters) 
   const float c = 0.999f, d = 1e-3f;
   const f2 pc = {c, c}, pd = {d, d};
   const f2 sc = {0.5f, 0.25f};
+  double d0 = a0, d1 = a1 * 0.5, d2 = a2 * 0.25, d3 = a3 * 0.125, d4 = 1.0 + a4 * 1e-3, d5 = a5, d6 = a6 * 0.5, d7 = a7;
   const long long t0 = clock64();
   const long long w0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
@@ -65,6 +66,20 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters) 
       REP8(asm volatile("v_pk_fma_f32 %0, %4, %5, %0\n v_pk_fma_f32 %1, %5, %6, %1\n v_pk_fma_f32 %2, %6, %7, %2\n v_pk_fma_f32 %3, %7, %4, %3\n"
                         "v_pk_fma_f32 %0, %6, %4, %0\n v_pk_fma_f32 %1, %7, %5, %1\n v_pk_fma_f32 %2, %4, %6, %2\n v_pk_fma_f32 %3, %5, %7, %3\n"
                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7));)
+    } else if (MODE == 14) {  // v_fma_f64, three distinct operands
+      REP8(asm volatile("v_fma_f64 %0, %1, %2, %3\n v_fma_f64 %1, %2, %3, %4\n v_fma_f64 %2, %3, %4, %5\n v_fma_f64 %3, %4, %5, %6\n"
+                        "v_fma_f64 %4, %5, %6, %7\n v_fma_f64 %5, %6, %7, %0\n v_fma_f64 %6, %7, %0, %1\n v_fma_f64 %7, %0, %1, %2\n"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));)
+    } else if (MODE == 15) {  // v_mul_f64 / v_add_f64
+      REP8(asm volatile("v_mul_f64 %0, %1, %2\n v_add_f64 %1, %2, %3\n v_mul_f64 %2, %3, %4\n v_add_f64 %3, %4, %5\n"
+                        "v_mul_f64 %4, %5, %6\n v_add_f64 %5, %6, %7\n v_mul_f64 %6, %7, %0\n v_add_f64 %7, %0, %1\n"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));)
+    } else if (MODE == 16) {  // v_cvt_f64_f32 / v_cvt_f32_f64 round trips
+      REP8(asm volatile("v_cvt_f64_f32 %0, %8\n v_cvt_f32_f64 %9, %1\n v_cvt_f64_f32 %2, %8\n v_cvt_f32_f64 %9, %3\n"
+                        "v_cvt_f64_f32 %4, %8\n v_cvt_f32_f64 %9, %5\n v_cvt_f64_f32 %6, %8\n v_cvt_f32_f64 %9, %7\n"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(a0), "+v"(a1));)
+    } else if (MODE == 17) {  // dependent v_fma_f64
+      REP64(asm volatile("v_fma_f64 %0, %0, %1, %2\n" : "+v"(d0) : "v"(d1), "v"(d2));)
     } else if (MODE == 13) {  // v_pk_fma_f32 with an SGPR-pair operand: a * s + c
       REP8(asm volatile("v_pk_fma_f32 %0, %1, %8, %2\n v_pk_fma_f32 %1, %2, %8, %3\n v_pk_fma_f32 %2, %3, %8, %4\n v_pk_fma_f32 %3, %4, %8, %5\n"
                         "v_pk_fma_f32 %4, %5, %8, %6\n v_pk_fma_f32 %5, %6, %8, %7\n v_pk_fma_f32 %6, %7, %8, %0\n v_pk_fma_f32 %7, %0, %8, %1\n"
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters) 
   }
   const long long t1 = clock64();
   const long long w1 = wall_clock64();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     cyc[0] = t1 - t0;
     cyc[1] = w1 - w0;
@@ -122,6 +137,10 @@ int main() {
     run<13>("v_pk_fma_f32 a*sgpr+c", w, out, cyc);
     run<10>("v_pk_mul/add_f32 2 distinct", w, out, cyc);
     run<11>("v_fma_f32 3 distinct operands", w, out, cyc);
+    run<14>("v_fma_f64 3 distinct operands", w, out, cyc);
+    run<17>("v_fma_f64 dependent", w, out, cyc);
+    run<15>("v_mul/add_f64", w, out, cyc);
+    run<16>("v_cvt f64<->f32", w, out, cyc);
   }
   return 0;
 }
