@@ -269,6 +269,10 @@ int tq_cosmos_step(const tq_cosmos_args* a, void* stream);
  * reading elbo_out / the per-AOI and global parameters.  prev == NULL: nothing pending (first step). */
 int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
 int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
+/* AOI-sharded runs: everything that follows the all-reduce of gsum (tq_cosmos_globals_grad + tq_cosmos_adam) in one
+ * single-workgroup launch, plus -- if `next` is given (full-batch steps) -- the global draws of the next step
+ * (tq_cosmos_sample_globals(next)), which need the global parameters this call updates. */
+int tq_cosmos_tail_reduced(const tq_cosmos_args* a, const tq_cosmos_args* next, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------

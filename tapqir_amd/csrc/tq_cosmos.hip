@@ -83,28 +83,6 @@ __global__ __launch_bounds__(256) void tq_aoi_kernel(const tq_cosmos_args a, con
   }
 }
 
-// ---- finish the cross-unit sums in fp64 (single workgroup) -----------------------------------------------
-__global__ __launch_bounds__(256) void tq_reduce_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
-  __shared__ double s_red[256];
-  const int nq = tq_num_gsum(a);
-  for (int j = 0; j < nq; ++j) {
-    double s = 0.0;
-    for (int64_t r = threadIdx.x; r < nblk; r += 256) s += (double)a.blk_part[r * nq + j];
-    if (j == TQ_GS_ELBO) {
-      const int nac = a.nb * a.C;
-      for (int r = threadIdx.x; r < nac; r += 256) s += (double)a.aoi_part[2 * B + r];
-    }
-    s_red[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) a.gsum[j] = s_red[0];
-    __syncthreads();
-  }
-}
-
 // one single-wave workgroup per global site: the fp64 special functions get the full register file
 // (no spills, hence no scratch memory: a per-lane scratch request is sized by the runtime for the
 // whole device and can push a dispatch onto the slow allocate-per-dispatch path)
@@ -135,9 +113,24 @@ __device__ __forceinline__ double tq_wave_sum_d(double v) {
   return v;
 }
 
-// body for ONE workgroup of 256 threads; s_w / s_e are its shared scratch
-__device__ __forceinline__ void tq_reduce_globals_body(const tq_cosmos_args& a, const int64_t nblk, const int64_t B,
-                                                       double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+// global sites (one lane of a wave per site, round-robin over the 4 waves) and the total ELBO from the finished sums
+__device__ __forceinline__ void tq_globals_from_gsum_body(const tq_cosmos_args& a, double* s_e) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ns = tq_num_gsites(a);
+  if (lane == 0)
+    for (int s = wave; s < ns; s += 4) s_e[s] = tq_body_globals_grad(a, s);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double eg = 0.0;
+    for (int j = 0; j < ns; ++j) eg += s_e[j];
+    a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
+  }
+}
+
+// cross-unit sums in fp64 by ONE workgroup of 256 threads (s_w: its shared scratch): per-workgroup rows of the unit
+// kernel + per-AOI ELBO parts -> gsum
+__device__ __forceinline__ void tq_reduce_sums_body(const tq_cosmos_args& a, const int64_t nblk, const int64_t B,
+                                                    double (*s_w)[TQ_MAX_NGSUM]) {
   const int nq = tq_num_gsum(a);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // every thread walks the rows once, carrying all columns (nq <= 15); then shuffle + 4-way LDS sum
@@ -160,23 +153,46 @@ __device__ __forceinline__ void tq_reduce_globals_body(const tq_cosmos_args& a, 
   }
   __syncthreads();
   if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+}
+
+// sums, then the global sites and the total ELBO (single-GPU steps: no all-reduce in between)
+__device__ __forceinline__ void tq_reduce_globals_body(const tq_cosmos_args& a, const int64_t nblk, const int64_t B,
+                                                       double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+  tq_reduce_sums_body(a, nblk, B, s_w);
   __threadfence_block();
   __syncthreads();
-  const int ns = tq_num_gsites(a);
-  if (lane == 0)
-    for (int s = wave; s < ns; s += 4) s_e[s] = tq_body_globals_grad(a, s);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double eg = 0.0;
-    for (int j = 0; j < ns; ++j) eg += s_e[j];
-    a.elbo_out[0] = a.gsum[TQ_GS_ELBO] + (double)a.global_weight * eg;
-  }
+  tq_globals_from_gsum_body(a, s_e);
+}
+
+// ---- finish the cross-unit sums in fp64 (single workgroup; sharded runs all-reduce gsum after it) ------------------
+__global__ __launch_bounds__(256) void tq_reduce_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
+  __shared__ double s_w[4][TQ_MAX_NGSUM];
+  tq_reduce_sums_body(a, nblk, B, s_w);
 }
 
 __global__ __launch_bounds__(256) void tq_reduce_globals_kernel(const tq_cosmos_args a, const int64_t nblk, const int64_t B) {
   __shared__ double s_w[4][TQ_MAX_NGSUM];
   __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
   tq_reduce_globals_body(a, nblk, B, s_w, s_e);
+}
+
+// AOI-sharded runs: everything of a step that follows the all-reduce of gsum, in one single-workgroup launch -- global
+// sites, total ELBO, Adam of the per-AOI / global parameters -- and, if `has_next`, the global draws of the next step.
+__global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_args a, const tq_cosmos_args next,
+                                                              const int has_next) {
+  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+  tq_globals_from_gsum_body(a, s_e);
+  __syncthreads();
+  const int64_t total = tq_num_params(a);
+  const int64_t first = a.fuse_adam ? tq_aoi_base(a) : total;  // minibatch steps: the dense Adam is its own launch
+  for (int64_t j = first + threadIdx.x; j < total; j += 256) tq_body_adam(a, j);
+  if (has_next) {
+    __threadfence();
+    __syncthreads();
+    const int ns = tq_num_gsites(next);
+    if ((threadIdx.x & 63) == 0)
+      for (int s = threadIdx.x >> 6; s < ns; s += 4) tq_body_sample_globals(next, s);
+  }
 }
 
 // Full-batch pipeline (tq_cosmos_step_overlapped): the local guide sampling of step t, with ONE extra workgroup (block (0, 0),
@@ -398,6 +414,23 @@ extern "C" int tq_cosmos_tail(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "tail")) return rc;
   if (int rc = launch_reduce_globals(a, (hipStream_t)stream)) return rc;
   return tq_cosmos_adam(a, stream);
+}
+
+extern "C" int tq_cosmos_tail_reduced(const tq_cosmos_args* a, const tq_cosmos_args* next, void* stream) {
+  if (int rc = check_args(a, "tail_reduced")) return rc;
+  if (next)
+    if (int rc = check_args(next, "tail_reduced (next)")) return rc;
+  if (!a->grad || !a->gsum || !a->elbo_out || !a->exp_avg || !a->exp_avg_sq) {
+    tq_set_error("tq_cosmos_tail_reduced: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  if (next && !a->fuse_adam) {
+    tq_set_error("tq_cosmos_tail_reduced: the next step's global draws need this step's Adam to be complete (fuse_adam steps only)");
+    return TQ_ERR_ARG;
+  }
+  hipLaunchKernelGGL(tq_tail_reduced_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, next ? *next : *a, next ? 1 : 0);
+  if (int rc = check_launch("tq_tail_reduced_kernel")) return rc;
+  return a->fuse_adam ? TQ_OK : tq_cosmos_adam(a, stream);
 }
 
 extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {

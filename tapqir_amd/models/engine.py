@@ -229,8 +229,9 @@ class CosmosEngine:
                 pending = None
             self.call("cosmos_sample_locals", a)
             if pending is not None:
-                self._finish_pending()
-            self.call("cosmos_sample_globals", a)
+                self._finish_pending(next_args=a)  # ... and draws this step's global sites in the same launch
+            else:
+                self.call("cosmos_sample_globals", a)
             self.call("cosmos_elbo_grads", a)
             handle = allreduce(self.gsum) if allreduce is not None else None
             if handle is not None and hasattr(handle, "wait") and a.fuse_adam:
@@ -238,19 +239,25 @@ class CosmosEngine:
             else:
                 if handle is not None and hasattr(handle, "wait"):
                     handle.wait()
-                self.call("cosmos_globals_grad", a)
-                self.call("cosmos_adam", a)
+                self._tail_reduced(a, None)
         self.adam_step += 1
 
-    def _finish_pending(self):
+    def _tail_reduced(self, a, next_args):
+        """Everything of step `a` after the all-reduce (one launch), plus the global draws of `next_args`."""
+        nxt = None if next_args is None else C.byref(next_args)
+        if self._hostcheck:
+            self.lib.hc_cosmos_tail_reduced(C.byref(a), nxt)
+        else:
+            _lib.check(self.lib.tq_cosmos_tail_reduced(C.byref(a), nxt, self._stream()), "tq_cosmos_tail_reduced")
+
+    def _finish_pending(self, next_args=None):
         """Global tail of a step whose all-reduce was left in flight."""
         if self._pending is None:
             return
         a, handle = self._pending
         self._pending = None
         handle.wait()  # the current stream waits for the collective
-        self.call("cosmos_globals_grad", a)
-        self.call("cosmos_adam", a)
+        self._tail_reduced(a, next_args)
 
     def _finish_tail(self):
         """Tail of a pipelined full-batch step (tq_cosmos_step_overlapped left it pending)."""

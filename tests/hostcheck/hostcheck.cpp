@@ -365,6 +365,14 @@ void hc_cosmos_globals_grad(const tq_cosmos_args* a) {
   for (int s = 0; s < tq_num_gsites(*a); ++s) eg += tq_body_globals_grad(*a, s);
   a->elbo_out[0] = a->gsum[TQ_GS_ELBO] + (double)a->global_weight * eg;
 }
+void hc_cosmos_adam(const tq_cosmos_args* a);
+void hc_cosmos_sample_globals(const tq_cosmos_args* a);
+// everything after the all-reduce of gsum (+ the next step's global draws): tq_cosmos_tail_reduced
+void hc_cosmos_tail_reduced(const tq_cosmos_args* a, const tq_cosmos_args* next) {
+  hc_cosmos_globals_grad(a);
+  hc_cosmos_adam(a);
+  if (next) hc_cosmos_sample_globals(next);
+}
 void hc_cosmos_adam(const tq_cosmos_args* a) {
   const int64_t total = tq_num_params(*a);
   for (int64_t j = a->fuse_adam ? tq_aoi_base(*a) : 0; j < total; ++j) tq_body_adam(*a, j);
