@@ -255,13 +255,16 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
                                               float ln_g, const float* W) {
   const uint32_t magic = (1u << 20) / (uint32_t)P + 1u;  // exact pix / P for pix < 4096, P <= 64
   const float off0 = a.offset_samples[0];
+  const float c0 = 0.5f * (float)(P - 1);
   TqOffsetInfo h;
   if (!ONE_OFFSET) tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
   for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
     const int j = (int)(((uint32_t)pix * magic) >> 20);
     const int ic = pix - j * P;
     const float D = s_tile[pix];
-    const float fic = (float)ic, fj = (float)j;
+    // spot-weighted moments are taken about the tile centre: |coordinate| <= P/2 instead of P keeps the cancellation
+    // in the width gradient (second moment minus 2 w^2) four times smaller in fp32
+    const float fic = (float)ic - c0, fj = (float)j - c0;
     float spot[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) spot[k] = amph[k] * s_fac[(2 * k) * TQ_MAX_P + ic] * s_fac[(2 * k + 1) * TQ_MAX_P + j];
@@ -387,7 +390,15 @@ __global__ __launch_bounds__(TQ_BLOCK, TQ_PIX_WAVES) void tq_ksmogn_kernel(const
     bad = a.pixstats[2 * a.stats_stride + u] > 0.0f;
     tq_pixel_assemble_one_offset<K, BWD>(a, A, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
   }
-  if (live && r == 0) tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cx, cy, (float)npix, S_v, bad);
+  if (live && r == 0) {
+    float cxs[K], cys[K];  // the moments were taken about the tile centre (tq_pixel_loop)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      cxs[k] = cx[k] - 0.5f * (float)(P - 1);
+      cys[k] = cy[k] - 0.5f * (float)(P - 1);
+    }
+    tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
+  }
 }
 
 // =============================================================================================
@@ -410,6 +421,7 @@ __device__ __forceinline__ void tq_il_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn
   TqOffsetInfo h;
   if (!ONE_OFFSET) tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
   int ic = 0, jr = 0;  // wave-uniform pixel coordinates
+  const float c0 = 0.5f * (float)(P - 1);  // spot-weighted moments are taken about the tile centre (see tq_pixel_loop)
   float fj = 0.0f, agy[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) agy[k] = amph[k] * __builtin_amdgcn_exp2f(cy[k] * cy[k] * nl2[k]);
@@ -427,8 +439,8 @@ __device__ __forceinline__ void tq_il_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn
           const float dx = fic - cx[k];
           spot[k] = agy[k] * __builtin_amdgcn_exp2f(dx * dx * nl2[k]);
         }
-        if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, d4[e] - off0, b, spot, W, fic, fj, g, rg, ln_g);
-        else tq_pixel_multi_offset<K, BWD, FAST>(A, a, h, d4[e], ln_g, b, spot, W, fic, fj, g, rg);
+        if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, d4[e] - off0, b, spot, W, fic - c0, fj - c0, g, rg, ln_g);
+        else tq_pixel_multi_offset<K, BWD, FAST>(A, a, h, d4[e], ln_g, b, spot, W, fic - c0, fj - c0, g, rg);
         if (++ic == P) {  // next row: refresh the y-factors
           ic = 0;
           ++jr;
@@ -504,7 +516,15 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il_kernel(const tq_ksmogn_args 
     bad = a.pixstats[2 * a.stats_stride + i] > 0.0f;
     tq_pixel_assemble_one_offset<K, BWD>(a, A, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
   }
-  if (live) tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cx, cy, (float)npix, S_v, bad);
+  if (live) {
+    float cxs[K], cys[K];  // the moments were taken about the tile centre (tq_il_pixel_loop)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      cxs[k] = cx[k] - 0.5f * (float)(P - 1);
+      cys[k] = cy[k] - 0.5f * (float)(P - 1);
+    }
+    tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
+  }
 }
 
 // =============================================================================================
@@ -584,7 +604,7 @@ __device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 
           if ((mi >> k) & 1) q[k] += cw;
       }
     }
-    const tq_f2 fic = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)};
+    const tq_f2 fic = (tq_f2){(float)(2 * ip) - 0.5f * (float)(P - 1), (float)(2 * ip + 1) - 0.5f * (float)(P - 1)};
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (COLACC) {
@@ -593,7 +613,7 @@ __device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 
       } else {
         const tq_f2 aq = q[k] * spot[k];
         A.S0r[k] = first_in_row ? aq : A.S0r[k] + aq;
-        A.Sx[k] += aq * fic;
+        A.Sx[k] += aq * fic;  // fic: column coordinates about the tile centre (compile-time constants)
         A.Sxx[k] += aq * (fic * fic);
       }
     }
@@ -638,7 +658,8 @@ __global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
 
   TqPixAcc<K> S;
   tq_acc_zero<K>(S);
-  if (__all(b * rg >= TQ_FAST_ALPHA)) {
+  const bool fastpath = __all(b * rg >= TQ_FAST_ALPHA);
+  if (fastpath) {
     // the x-factor of a spot does not depend on the row: P values per spot, kept in registers
     tq_f2 ex[K][P / 2];
     float sum_ex[K], sum_gy[K];
@@ -689,11 +710,11 @@ __global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) {
         const float fj = (float)(body * R + rr);
-        float agy[K];
+        float agy[K], dyk[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const float dy = fj - cy[k];
-          agy[k] = amph[k] * __builtin_amdgcn_exp2f(dy * dy * nl2[k]);
+          dyk[k] = fj - cy[k];
+          agy[k] = amph[k] * __builtin_amdgcn_exp2f(dyk[k] * dyk[k] * nl2[k]);
           sum_gy[k] += agy[k];
         }
 #pragma unroll
@@ -709,12 +730,12 @@ __global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
           tq_pixel_pair<K, P, BWD, COLACC>(A, D - off0, b, spot, W, ip, ip == 0, c);
         }
         if (BWD) {
-          const float fj2 = fj * fj;
+          // y-moments about the spot's own centre (the row offset dy is at hand): no cancellation later
 #pragma unroll
           for (int k = 0; k < K; ++k) {
             if (!COLACC) A.S0[k] += A.S0r[k];
-            A.Sy[k] += A.S0r[k] * fj;
-            A.Syy[k] += A.S0r[k] * fj2;
+            A.Sy[k] += A.S0r[k] * dyk[k];
+            A.Syy[k] += A.S0r[k] * (dyk[k] * dyk[k]);
           }
         }
       }
@@ -733,14 +754,14 @@ __global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         tq_f2 s0 = A.S0[k], sx = A.Sx[k], sxx = A.Sxx[k];
-        if (COLACC) {
+        if (COLACC) {  // column sums folded with the column offsets from the spot's own centre
           s0 = sx = sxx = tq2(0.0f);
 #pragma unroll
           for (int ip = 0; ip < P / 2; ++ip) {
-            const tq_f2 fic = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)};
+            const tq_f2 dxc = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)} - cx[k];
             s0 += A.col[k][ip];
-            sx += A.col[k][ip] * fic;
-            sxx += A.col[k][ip] * (fic * fic);
+            sx += A.col[k][ip] * dxc;
+            sxx += A.col[k][ip] * (dxc * dxc);
           }
         }
         S.S0[k] = (s0.x + s0.y) * TQ_LN2;
@@ -758,13 +779,17 @@ __global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
   const bool bad = a.pixstats[2 * a.stats_stride + i] > 0.0f;
   tq_pixel_assemble_one_offset<K, BWD>(a, S, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
   if (live) {
-    float hk[K], wk[K];
+    float hk[K], wk[K], cxs[K], cys[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       hk[k] = a.height[k * B + i];
       wk[k] = a.width[k * B + i];
+      // reference points of the moments: the packed loop centres y on the spot and x on the spot (column sums) or on
+      // the tile centre; the scalar fallback loop uses the tile centre for both
+      cxs[k] = fastpath ? (COLACC ? 0.0f : cx[k] - 0.5f * (float)(P - 1)) : cx[k] - 0.5f * (float)(P - 1);
+      cys[k] = fastpath ? 0.0f : cy[k] - 0.5f * (float)(P - 1);
     }
-    tq_pixel_store<K, true, BWD>(a, B, i, S, W, b, rg, hk, wk, cx, cy, (float)npix, S_v, bad);
+    tq_pixel_store<K, true, BWD>(a, B, i, S, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
   }
 }
 
@@ -905,6 +930,7 @@ __device__ __forceinline__ void tq_il2m_pixel_loop(TqPixAcc<K>& A, const tq_ksmo
                                                    const float* nl2, const float* cx, const float* cy, float g,
                                                    float rg, float ln_g, const float* W) {
   const int npix4 = (P * P) >> 2;
+  const float c0 = 0.5f * (float)(P - 1);  // spot-weighted moments are taken about the tile centre
   int ic = 0, jr = 0;  // wave-uniform coordinates of the next pixel pair (P even: a pair never straddles rows)
   float agy[K];
 #pragma unroll
@@ -924,7 +950,7 @@ __device__ __forceinline__ void tq_il2m_pixel_loop(TqPixAcc<K>& A, const tq_ksmo
         const tq_f2 dx = fic - cx[k];
         spot[k] = agy[k] * tq2_exp2(dx * dx * nl2[k]);
       }
-      tq_pair_multi_offset<K, BWD, WFAC>(A, a, h, s_tab, fast, D, b, spot, W, fic, fj, g, rg, ln_g);
+      tq_pair_multi_offset<K, BWD, WFAC>(A, a, h, s_tab, fast, D, b, spot, W, fic - c0, fj - c0, g, rg, ln_g);
       ic += 2;
       if (ic == P) {
         ic = 0;
@@ -991,7 +1017,15 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il2m_kernel(const tq_ksmogn_arg
   const bool fast = __all(b * rg >= TQ_FAST_ALPHA);
   if (wfac) tq_il2m_pixel_loop<K, BWD, true>(A, a, h, s_tab, fast, src, P, b, amph, nl2, cx, cy, g, rg, ln_g, W);
   else tq_il2m_pixel_loop<K, BWD, false>(A, a, h, s_tab, fast, src, P, b, amph, nl2, cx, cy, g, rg, ln_g, W);
-  if (live) tq_pixel_store<K, false, BWD>(a, B, i, A, W, b, rg, hk, wk, cx, cy, (float)npix, 0.0f, false);
+  if (live) {
+    float cxs[K], cys[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      cxs[k] = cx[k] - 0.5f * (float)(P - 1);
+      cys[k] = cy[k] - 0.5f * (float)(P - 1);
+    }
+    tq_pixel_store<K, false, BWD>(a, B, i, A, W, b, rg, hk, wk, cxs, cys, (float)npix, 0.0f, false);
+  }
 }
 
 // (U, npix) row-major tiles -> the interleaved layout above; out holds ceil(U/64) * npix4 * 256 floats

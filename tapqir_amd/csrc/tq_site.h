@@ -84,11 +84,26 @@ TQ_HD void tq_beta_logpdf(float t, float c1, float c0, float* lp, float* d_t, fl
   float lg1, dg1, lg0, dg0, lgt, dgt;
   tq_lgamma_digamma(c1, &lg1, &dg1);
   tq_lgamma_digamma(c0, &lg0, &dg0);
-  tq_lgamma_digamma(c1 + c0, &lgt, &dgt);
+  const float T = c1 + c0;
+  tq_lgamma_digamma(T, &lgt, &dgt);
   *lp = (c1 - 1.0f) * lt + (c0 - 1.0f) * l1t + lgt - lg1 - lg0;
   *d_t = (c1 - 1.0f) * TQ_FRCP(t) - (c0 - 1.0f) * TQ_FRCP(1.0f - t);
-  *d_c1 = lt - dg1 + dgt;
-  *d_c0 = l1t - dg0 + dgt;
+  if (c1 >= 8.0f && c0 >= 8.0f) {
+    // d lp / d c1 = ln t - psi(c1) + psi(T) is O(|t - mean| / mean + 1/c) while its three terms are O(ln c): with
+    // psi(a) = ln a - 1/(2a) + S'(a) the logarithms combine to ln(t T / c1) = log1p((t T - c1) / c1), and likewise
+    // for c0 with (1-t) T - c0 = -(t T - c1): no cancellation left
+    const float r1 = TQ_FRCP(c1), r0 = TQ_FRCP(c0), rT = TQ_FRCP(T);
+    const float num = t * T - c1;
+    float S_, dS1, dS0, dST;
+    tq_binet_series<float>(c1, r1, &S_, &dS1);
+    tq_binet_series<float>(c0, r0, &S_, &dS0);
+    tq_binet_series<float>(T, rT, &S_, &dST);
+    *d_c1 = log1pf(num * r1) + 0.5f * (r1 - rT) + (dST - dS1);
+    *d_c0 = log1pf(-num * r0) + 0.5f * (r0 - rT) + (dST - dS0);
+  } else {
+    *d_c1 = lt - dg1 + dgt;
+    *d_c0 = l1t - dg0 + dgt;
+  }
 }
 
 // ---- guide-site terms ----------------------------------------------------------------------------

@@ -150,12 +150,14 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
           for (int k = 0; k < K; ++k)
             if ((mi >> k) & 1) q[k] += cw;
         }
-        const float r2 = fic * fic + fj * fj;
+        const float c0 = 0.5f * (float)(P - 1);  // moments about the tile centre, as the device kernels take them
+        const float fx = fic - c0, fy = fj - c0;
+        const float r2 = fx * fx + fy * fy;
         for (int k = 0; k < K; ++k) {
           const float aq = q[k] * spot[k];
           S0[k] += aq;
-          Sx[k] += aq * fic;
-          Sy[k] += aq * fj;
+          Sx[k] += aq * fx;
+          Sy[k] += aq * fy;
           Sr[k] += aq * r2;
         }
       }
@@ -194,8 +196,9 @@ static void ksmogn_host(const tq_ksmogn_args& a) {
       a.g_gain[i] = (float)(-z * acc_g * rg);
       for (int k = 0; k < K; ++k) {
         const double rw = 1.0 / wk[k];
-        const double S1x = Sx[k] - cx[k] * S0[k], S1y = Sy[k] - cy[k] * S0[k];
-        const double S2 = Sr[k] - 2.0 * (cx[k] * Sx[k] + cy[k] * Sy[k]) + ((double)cx[k] * cx[k] + (double)cy[k] * cy[k]) * S0[k];
+        const double c0 = 0.5 * (P - 1), ccx = cx[k] - c0, ccy = cy[k] - c0;
+        const double S1x = Sx[k] - ccx * S0[k], S1y = Sy[k] - ccy * S0[k];
+        const double S2 = Sr[k] - 2.0 * (ccx * Sx[k] + ccy * Sy[k]) + (ccx * ccx + ccy * ccy) * S0[k];
         a.g_height[k * B + i] = (float)(z * S0[k] * rg / hk[k]);
         a.g_x[k * B + i] = (float)(z * rg * S1x * rw * rw);
         a.g_y[k * B + i] = (float)(z * rg * S1y * rw * rw);
