@@ -78,29 +78,40 @@ TQ_HD void tq_gamma_logpdf(float v, float loc, float beta, float* lp, float* d_v
   *d_beta = loc - v;                 // = alpha / beta - v
 }
 
+// ln(1 + u) with the rounding of 1 + u compensated (|u| < 1/2): one hardware log, one reciprocal
+TQ_HD float tq_log1p_small(float u) {
+  const float w = 1.0f + u;
+  return TQ_FLOG(w) - ((w - 1.0f) - u) * TQ_FRCP(w);
+}
+
 // Beta(t; c1, c0)
 TQ_HD void tq_beta_logpdf(float t, float c1, float c0, float* lp, float* d_t, float* d_c1, float* d_c0) {
-  const float lt = TQ_FLOG(t), l1t = TQ_FLOG(1.0f - t);
-  float lg1, dg1, lg0, dg0, lgt, dgt;
-  tq_lgamma_digamma(c1, &lg1, &dg1);
-  tq_lgamma_digamma(c0, &lg0, &dg0);
   const float T = c1 + c0;
-  tq_lgamma_digamma(T, &lgt, &dgt);
-  *lp = (c1 - 1.0f) * lt + (c0 - 1.0f) * l1t + lgt - lg1 - lg0;
   *d_t = (c1 - 1.0f) * TQ_FRCP(t) - (c0 - 1.0f) * TQ_FRCP(1.0f - t);
   if (c1 >= 8.0f && c0 >= 8.0f) {
-    // d lp / d c1 = ln t - psi(c1) + psi(T) is O(|t - mean| / mean + 1/c) while its three terms are O(ln c): with
-    // psi(a) = ln a - 1/(2a) + S'(a) the logarithms combine to ln(t T / c1) = log1p((t T - c1) / c1), and likewise
-    // for c0 with (1-t) T - c0 = -(t T - c1): no cancellation left
+    // Binet form throughout: lgamma(a) = (a - 1/2) ln a - a + ln sqrt(2 pi) + S(a), psi(a) = ln a - 1/(2a) + S'(a).
+    // d lp / d c1 = ln t - psi(c1) + psi(T) is O(|t - mean| / mean + 1/c) while its three terms are O(ln c): the
+    // logarithms combine to ln(t T / c1) = log1p((t T - c1) / c1), and likewise for c0 with (1-t) T - c0 = -(t T - c1)
     const float r1 = TQ_FRCP(c1), r0 = TQ_FRCP(c0), rT = TQ_FRCP(T);
+    float S1, dS1, S0, dS0, ST, dST;
+    tq_binet_series<float>(c1, r1, &S1, &dS1);
+    tq_binet_series<float>(c0, r0, &S0, &dS0);
+    tq_binet_series<float>(T, rT, &ST, &dST);
     const float num = t * T - c1;
-    float S_, dS1, dS0, dST;
-    tq_binet_series<float>(c1, r1, &S_, &dS1);
-    tq_binet_series<float>(c0, r0, &S_, &dS0);
-    tq_binet_series<float>(T, rT, &S_, &dST);
-    *d_c1 = log1pf(num * r1) + 0.5f * (r1 - rT) + (dST - dS1);
-    *d_c0 = log1pf(-num * r0) + 0.5f * (r0 - rT) + (dST - dS0);
+    const float u1 = tq_log1p_small(num * r1), u0 = tq_log1p_small(-num * r0);  // ln(t T / c1), ln((1-t) T / c0)
+    // (c1-1) ln t + (c0-1) ln(1-t) + lgamma(T) - lgamma(c1) - lgamma(c0) with ln t = u1 + ln(c1/T) etc.: the O(c ln c)
+    // terms cancel analytically, leaving (c1-1) u1 + (c0-1) u0 + (3/2) ln T - (1/2)(ln c1 + ln c0) - ln sqrt(2 pi) + S terms
+    *lp = ((c1 - 1.0f) * u1 + (c0 - 1.0f) * u0) + (1.5f * TQ_FLOG(T) - 0.5f * (TQ_FLOG(c1) + TQ_FLOG(c0))) - TQ_LN_SQRT_2PI +
+          (ST - S1 - S0);
+    *d_c1 = u1 + 0.5f * (r1 - rT) + (dST - dS1);
+    *d_c0 = u0 + 0.5f * (r0 - rT) + (dST - dS0);
   } else {
+    const float lt = TQ_FLOG(t), l1t = TQ_FLOG(1.0f - t);
+    float lg1, dg1, lg0, dg0, lgt, dgt;
+    tq_lgamma_digamma(c1, &lg1, &dg1);
+    tq_lgamma_digamma(c0, &lg0, &dg0);
+    tq_lgamma_digamma(T, &lgt, &dgt);
+    *lp = (c1 - 1.0f) * lt + (c0 - 1.0f) * l1t + lgt - lg1 - lg0;
     *d_c1 = lt - dg1 + dgt;
     *d_c0 = l1t - dg0 + dgt;
   }
