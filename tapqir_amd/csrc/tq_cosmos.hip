@@ -61,15 +61,14 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_kernel(const tq_cosmos_
   }
 }
 
-// ---- per-AOI terms: one wave per (a, c), lanes stride the frames --------------------------------------
+// ---- per-AOI terms: one workgroup per (a, c), threads stride the frames ------------------------------------
 __global__ __launch_bounds__(256) void tq_aoi_kernel(const tq_cosmos_args a, const int64_t B) {
-  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int lane = threadIdx.x & 63;
-  const int nac = a.nb * a.C;
-  if (wave >= nac) return;
-  const int ai = wave / a.C, c = wave % a.C;
+  __shared__ float s_sum[4][2];
+  const int ac = blockIdx.x;  // < nb * C
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ai = ac / a.C, c = ac % a.C;
   float s1 = 0.0f, s2 = 0.0f;
-  for (int b = lane; b < a.fb; b += 64) {
+  for (int b = threadIdx.x; b < a.fb; b += 256) {
     const int64_t i = ((int64_t)ai * a.fb + b) * a.C + c;
     s1 += a.aoi_part[i];
     s2 += a.aoi_part[B + i];
@@ -77,9 +76,15 @@ __global__ __launch_bounds__(256) void tq_aoi_kernel(const tq_cosmos_args a, con
   s1 = tq_wave_sum(s1);
   s2 = tq_wave_sum(s2);
   if (lane == 0) {
+    s_sum[wave][0] = s1;
+    s_sum[wave][1] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     float e;
-    tq_body_aoi_finish(a, ai, c, s1, s2, &e);
-    a.aoi_part[2 * B + wave] = e;  // per-AOI prior part of the ELBO (row 2 is scratch, nb*C <= B)
+    tq_body_aoi_finish(a, ai, c, (s_sum[0][0] + s_sum[1][0]) + (s_sum[2][0] + s_sum[3][0]),
+                       (s_sum[0][1] + s_sum[1][1]) + (s_sum[2][1] + s_sum[3][1]), &e);
+    a.aoi_part[2 * B + ac] = e;  // per-AOI prior part of the ELBO (row 2 is scratch, nb*C <= B)
   }
 }
 
@@ -357,8 +362,7 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
   }
   if (int rc = check_launch("tq_unit_kernel")) return rc;
   // 3. per-AOI sites
-  const int64_t nwaves = (int64_t)a->nb * a->C;
-  hipLaunchKernelGGL(tq_aoi_kernel, dim3((unsigned)((nwaves * 64 + 255) / 256)), dim3(256), 0, st, *a, B);
+  hipLaunchKernelGGL(tq_aoi_kernel, dim3((unsigned)(a->nb * a->C)), dim3(256), 0, st, *a, B);
   if (int rc = check_launch("tq_aoi_kernel")) return rc;
   // 4. cross-unit sums
   if (!finish_sums) return TQ_OK;
