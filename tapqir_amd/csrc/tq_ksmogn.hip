@@ -621,7 +621,7 @@ __device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 
 }
 
 template <int K, int P, bool BWD>
-__global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
+__global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(const tq_ksmogn_args a, const int64_t B) {
   static_assert(P % 2 == 0 && (P * P) % 4 == 0, "packed kernel needs an even tile side");
   constexpr int M = 1 << K;
   constexpr int R = ((P / 2) % 2) ? 2 : 1;  // rows per loop body so that the body starts on a float4 boundary
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(co
   constexpr int NB = P / R;                 // bodies per tile
   constexpr int npix = P * P, npix4 = npix / 4;
   constexpr bool COLACC = BWD && (K * P <= 28);
-  const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;  // one wave per workgroup: no barriers, finest dispatch granularity
   const bool live = i_raw < B;
   const int64_t i = live ? i_raw : (B - 1);
   // idle lanes of the last workgroup read the LAST tile too: the interleaved buffer ends with its 64-tile block
@@ -1106,12 +1106,13 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
   if (a.images_il && !a.ndx && !a.fdx && a.nb == a.nb_full && a.fb == a.F && B >= a.il_min_units) {
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     if (ONE && (a.P == 14 || a.P == 20)) {
+      const dim3 grid1((unsigned)((B + 63) / 64)), block1(64);
       if (a.P == 14) {
-        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, true>), grid, block, 0, st, a, B);
-        else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, false>), grid, block, 0, st, a, B);
+        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, true>), grid1, block1, 0, st, a, B);
+        else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, false>), grid1, block1, 0, st, a, B);
       } else {
-        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, true>), grid, block, 0, st, a, B);
-        else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, false>), grid, block, 0, st, a, B);
+        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, true>), grid1, block1, 0, st, a, B);
+        else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 20, false>), grid1, block1, 0, st, a, B);
       }
       return launch_status("tq_ksmogn_il2_kernel");
     }
