@@ -273,6 +273,13 @@ int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
  * single-workgroup launch, plus -- if `next` is given (full-batch steps) -- the global draws of the next step
  * (tq_cosmos_sample_globals(next)), which need the global parameters this call updates. */
 int tq_cosmos_tail_reduced(const tq_cosmos_args* a, const tq_cosmos_args* next, void* stream);
+/* AOI-sharded pipeline: draw the local sites [site_begin, site_begin + site_count) of `a` (site order as in `lat`).
+ * With `prev` != NULL -- a full-batch step whose gsum the caller has all-reduced -- the same launch carries, as one extra
+ * workgroup, tq_cosmos_tail_reduced(prev, a): a sharded host draws the first sites of step t+1 while the all-reduce of
+ * step t is in flight, waits for it, and passes `prev` with the remaining sites, so that neither the collective nor the
+ * single-workgroup tail is exposed. */
+int tq_cosmos_sample_locals_range(const tq_cosmos_args* a, int32_t site_begin, int32_t site_count,
+                                  const tq_cosmos_args* prev, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------

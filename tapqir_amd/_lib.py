@@ -102,7 +102,7 @@ EXPORTS = [
     "tq_interleaved_floats", "tq_interleaved_floats_n", "tq_images_interleave_n", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced",
+    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
     "tq_cosmos_probs",
 ]
 
@@ -156,6 +156,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int
+    lib.tq_cosmos_sample_locals_range.argtypes = [C.POINTER(CosmosArgs), C.c_int32, C.c_int32, C.POINTER(CosmosArgs), C.c_void_p]
+    lib.tq_cosmos_sample_locals_range.restype = C.c_int
     lib.tq_cosmos_probs.argtypes = [C.POINTER(ProbsArgs), C.c_void_p]
     lib.tq_cosmos_probs.restype = C.c_int
     _lib = lib

@@ -29,9 +29,9 @@ __global__ __launch_bounds__(64) void tq_sample_globals_kernel(const tq_cosmos_a
 }
 
 // grid.y = site: the site kind (Gamma / AffineBeta, which parameter rows) is uniform per workgroup
-__global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t B) {
+__global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t B, const int site_begin) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) tq_body_site(a, (int)blockIdx.y, i);
+  if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y, i);
 }
 
 // ---- per-unit terms ------------------------------------------------------------------------------------
@@ -206,14 +206,17 @@ __global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_ar
 // sampling of the local sites reads local parameters only (already updated by the Adam fused into the unit kernel of
 // step t-1), so the ~35 us latency chain of the tail hides behind the ~14 000 sampling workgroups of the same launch.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tq_sample_locals_tail_kernel(
-    const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B) {
+    const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B, const int site_begin) {
+  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first), 2 = gsum of `prev` is complete
+  // (all-reduced by the caller): global sites onwards
   if (blockIdx.y == 0) {
     if (blockIdx.x != 0) return;
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
-      tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
+      if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
+      else tq_globals_from_gsum_body(prev, s_e);
       __syncthreads();
       const int64_t total = tq_num_params(prev);
       for (int64_t j = tq_aoi_base(prev) + threadIdx.x; j < total; j += 256) tq_body_adam(prev, j);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
     return;
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) tq_body_site(a, (int)blockIdx.y - 1, i);
+  if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y - 1, i);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -287,7 +290,7 @@ extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
   }
   const int64_t B = tq_batch_units(*a);
   hipLaunchKernelGGL(tq_sample_locals_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(1 + 4 * a->K)), dim3(256), 0,
-                     (hipStream_t)stream, *a, B);
+                     (hipStream_t)stream, *a, B, 0);
   return check_launch("tq_sample_locals_kernel");
 }
 
@@ -461,9 +464,38 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
   }
   const int64_t B = tq_batch_units(*a);
   hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(2 + 4 * a->K)), dim3(256), 0,
-                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? 1 : 0, B);
+                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? 1 : 0, B, 0);
   if (int rc = check_launch("tq_sample_locals_tail_kernel")) return rc;
   return elbo_grads_impl(a, stream, false);
+}
+
+// AOI-sharded pipeline: the local sites [site_begin, site_begin + site_count) of `a`; with `prev` (whose gsum the caller
+// has all-reduced) the launch also carries, as one extra workgroup, everything of `prev` after the all-reduce and the
+// global draws of `a` (tq_cosmos_tail_reduced(prev, a)).  A sharded host samples the first sites of step t+1 while the
+// all-reduce of step t is in flight, waits for it, and calls this with `prev` for the remaining sites.
+extern "C" int tq_cosmos_sample_locals_range(const tq_cosmos_args* a, int32_t site_begin, int32_t site_count,
+                                             const tq_cosmos_args* prev, void* stream) {
+  if (int rc = check_args(a, "sample_locals_range")) return rc;
+  if (prev)
+    if (int rc = check_args(prev, "sample_locals_range (prev)")) return rc;
+  if (!a->lat || !a->site || site_begin < 0 || site_count < 1 || site_begin + site_count > 1 + 4 * a->K) {
+    tq_set_error("tq_cosmos_sample_locals_range: bad site range or NULL lat/site");
+    return TQ_ERR_ARG;
+  }
+  if (prev && (!prev->fuse_adam || !prev->grad || !prev->gsum || !prev->elbo_out || !prev->exp_avg || !prev->exp_avg_sq)) {
+    tq_set_error("tq_cosmos_sample_locals_range: prev must be a full-batch (fuse_adam) step with grad/gsum/elbo_out/moments");
+    return TQ_ERR_ARG;
+  }
+  const int64_t B = tq_batch_units(*a);
+  const unsigned gx = (unsigned)((B + 255) / 256);
+  if (prev) {
+    hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3(gx, (unsigned)(site_count + 1)), dim3(256), 0, (hipStream_t)stream, *a,
+                       *prev, 2, B, (int)site_begin);
+    return check_launch("tq_sample_locals_tail_kernel");
+  }
+  hipLaunchKernelGGL(tq_sample_locals_kernel, dim3(gx, (unsigned)site_count), dim3(256), 0, (hipStream_t)stream, *a, B,
+                     (int)site_begin);
+  return check_launch("tq_sample_locals_kernel");
 }
 
 // ---- posterior read-out (cosmos.compute_probs) -------------------------------------------------------------

@@ -227,11 +227,24 @@ class CosmosEngine:
             if pending is not None and not a.fuse_adam:
                 self._finish_pending()  # a minibatch step samples after the dense Adam of the previous one
                 pending = None
-            self.call("cosmos_sample_locals", a)
-            if pending is not None:
-                self._finish_pending(next_args=a)  # ... and draws this step's global sites in the same launch
+            if pending is not None and not self._hostcheck:
+                # first half of the local sites while the all-reduce is in flight; the rest in a launch that also
+                # carries the pending step's post-all-reduce tail and this step's global draws
+                nsites = 1 + 4 * self.K
+                n1 = nsites // 2
+                prev, handle = self._pending
+                self._pending = None
+                _lib.check(self.lib.tq_cosmos_sample_locals_range(C.byref(a), 0, n1, None, self._stream()),
+                           "tq_cosmos_sample_locals_range")
+                handle.wait()  # the current stream waits for the collective
+                _lib.check(self.lib.tq_cosmos_sample_locals_range(C.byref(a), n1, nsites - n1, C.byref(prev), self._stream()),
+                           "tq_cosmos_sample_locals_range")
             else:
-                self.call("cosmos_sample_globals", a)
+                self.call("cosmos_sample_locals", a)
+                if pending is not None:
+                    self._finish_pending(next_args=a)  # ... and draws this step's global sites in the same launch
+                else:
+                    self.call("cosmos_sample_globals", a)
             self.call("cosmos_elbo_grads", a)
             handle = allreduce(self.gsum) if allreduce is not None else None
             if handle is not None and hasattr(handle, "wait") and a.fuse_adam:
