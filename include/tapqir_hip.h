@@ -307,6 +307,37 @@ typedef struct {
 
 int tq_cosmos_probs(const tq_probs_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Input side: AOI extraction from raw Glimpse frames.
+ * Replaces the per-frame / per-AOI loop of read_glimpse (tapqir/imscroll/glimpse_reader.py:358-392), the frame
+ * decode of GlimpseDataset.__getitem__ (168-186: big-endian int16 + 2^15) and the offset-region value counts
+ * (362-369), for one chunk of `nf` consecutive frames of one colour channel:
+ *
+ *   shiftx = rint(x - 0.5 (P - 1)),  shifty = rint(y - 0.5 (P - 1))       (Python round(): half to even, 374-375)
+ *   images[n, f0 + f, c, i, j]   = frame_f[shifty + i, shiftx + j] + 32768  (376-378)
+ *   target_xy[n, f0 + f, c, :]   = (x - shiftx, y - shifty)                 (379-384)
+ *   offset_hist[v]              += #{pixels == v in frame_f[offset_y : +offset_P, offset_x : +offset_P]}  (362-369)
+ *
+ * Integer work, bit-exact.  A crop that leaves the frame (the reference fails there with a numpy broadcasting
+ * ValueError) is skipped and counted in status[0]; the caller raises.  status[1] receives the smallest extracted
+ * pixel value (atomic min: initialise to INT32_MAX), which the offset post-processing needs (419-421).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t* frames;   /* nf frames of H*W big-endian int16: the bytes of the .glimpse file, unmodified */
+  const double* raw_xy;    /* (N, nf, 2) drift-corrected target positions (x, y) in frame pixels, float64 (347-350);
+                              16-byte aligned */
+  int32_t* images;         /* (N, F, C, P, P) out; only channel c of frames [f0, f0 + nf) is written */
+  double* target_xy;       /* (N, F, C, 2) out */
+  int64_t* offset_hist;    /* [65536] accumulated; NULL = no offset region in this call */
+  int32_t* status;         /* [2]: {crops outside the frame (accumulated), min pixel (atomic min)} */
+  int32_t H, W;            /* frame height, width (header.mat) */
+  int32_t N, F, C, P;
+  int32_t c, f0, nf;
+  int32_t offset_x, offset_y, offset_P;
+} tq_glimpse_args;
+
+int tq_glimpse_extract(const tq_glimpse_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,18 @@ class ProbsArgs(C.Structure):
     ]
 
 
+class GlimpseArgs(C.Structure):
+    """``tq_glimpse_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("frames", C.c_void_p), ("raw_xy", C.c_void_p), ("images", C.c_void_p), ("target_xy", C.c_void_p),
+        ("offset_hist", C.c_void_p), ("status", C.c_void_p),
+        ("H", C.c_int32), ("W", C.c_int32), ("N", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("P", C.c_int32),
+        ("c", C.c_int32), ("f0", C.c_int32), ("nf", C.c_int32),
+        ("offset_x", C.c_int32), ("offset_y", C.c_int32), ("offset_P", C.c_int32),
+    ]
+
+
 # every symbol include/tapqir_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "tq_version", "tq_last_error", "tq_ksmogn_log_prob", "tq_ksmogn_crosstalk_log_prob", "tq_crosstalk_param_count",
@@ -103,7 +115,7 @@ EXPORTS = [
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
-    "tq_cosmos_probs",
+    "tq_cosmos_probs", "tq_glimpse_extract",
 ]
 
 _lib = None
@@ -160,6 +172,8 @@ def load():
     lib.tq_cosmos_sample_locals_range.restype = C.c_int
     lib.tq_cosmos_probs.argtypes = [C.POINTER(ProbsArgs), C.c_void_p]
     lib.tq_cosmos_probs.restype = C.c_int
+    lib.tq_glimpse_extract.argtypes = [C.POINTER(GlimpseArgs), C.c_void_p]
+    lib.tq_glimpse_extract.restype = C.c_int
     _lib = lib
     return lib
 

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtapqir_hip.so")
-SOURCES = ["tq_ksmogn.hip", "tq_xtalk.hip", "tq_cosmos.hip"]
+SOURCES = ["tq_ksmogn.hip", "tq_xtalk.hip", "tq_cosmos.hip", "tq_glimpse.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed"]
 
 

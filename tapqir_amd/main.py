@@ -1,9 +1,10 @@
 """
-Command line of the MI355X build: the ``fit`` / ``stats`` / ``log`` commands of ``tapqir`` (tapqir/main.py:321-576,
-873-884, 1387-1488) over the same workspace (``<cd>/.tapqir/config.yaml``, ``loginfo``, ``<model>_model.tpqr``,
+Command line of the MI355X build: the ``glimpse`` / ``fit`` / ``stats`` / ``log`` commands of ``tapqir``
+(tapqir/main.py:66-318, 321-576, 873-884, 1387-1488) over the same workspace (``<cd>/.tapqir/config.yaml``, ``loginfo``, ``<model>_model.tpqr``,
 ``<model>_params.tpqr``, ``<model>_summary.csv``).  Options, defaults and exit codes (0 / 1) follow the reference;
-``--cpu`` exits with 1 because the SVI step has no CPU path here.  Data preparation (``glimpse``), plotting (``show``) and
-the kinetics commands are outside the hot-path scope of this build.
+``--cpu`` exits with 1 because the SVI step has no CPU path here.  ``glimpse`` takes its inputs from flags or from
+``config.yaml`` (there are no interactive prompts).  Plotting (``show``) and the kinetics commands are outside the
+hot-path scope of this build.
 
     python -m tapqir_amd --cd <dir> fit --model cosmos --cuda --num-iter 0 --no-input
 """
@@ -12,7 +13,7 @@ import logging
 import sys
 from enum import Enum
 from pathlib import Path
-from typing import Optional
+from typing import List, Optional
 
 import typer
 import yaml
@@ -62,6 +63,77 @@ def _build_model(name: str, logger, **settings):
     except (NotImplementedError, HipExtensionError):
         logger.exception(f"Model {name} is not available in this build")
         return None
+
+
+@app.command()
+def glimpse(
+    dataset: str = typer.Option(_default("dataset"), help="Dataset name"),
+    P: int = typer.Option(_default("P"), "--aoi-size", "-P", min=5, max=50, help="AOI image size - number of pixels along the axis"),
+    offset_x: int = typer.Option(_default("offset-x"), "--offset-x", min=0, help="x-axis position of the top-left corner of the offset region"),
+    offset_y: int = typer.Option(_default("offset-y"), "--offset-y", min=0, help="y-axis position of the top-left corner of the offset region"),
+    offset_P: int = typer.Option(_default("offset-P"), "--offset-P", min=5, help="Offset region size - number of pixels along the axis"),
+    bin_size: int = typer.Option(_default("bin-size"), "--bin-size", min=1, max=21, help="Offset histogram bin size (odd number)"),
+    frame_range: bool = typer.Option(_default("frame-range"), help="Specify frame range."),
+    frame_start: Optional[int] = typer.Option(_default("frame-start"), min=0, help="Starting frame."),
+    frame_end: Optional[int] = typer.Option(_default("frame-end"), min=1, help="Ending frame."),
+    use_offtarget: bool = typer.Option(_default("use-offtarget"), help="Use off-target AOI locations."),
+    num_channels: int = typer.Option(_default("num-channels"), "--num-channels", "-C", min=1, help="Number of color channels"),
+    name: Optional[List[str]] = typer.Option(None, help="Channel name (once per channel)"),
+    glimpse_folder: Optional[List[Path]] = typer.Option(None, exists=True, file_okay=False, resolve_path=True),
+    driftlist: Optional[List[Path]] = typer.Option(None, exists=True, dir_okay=False, resolve_path=True),
+    ontarget_aoiinfo: Optional[List[Path]] = typer.Option(None, exists=True, dir_okay=False, resolve_path=True),
+    offtarget_aoiinfo: Optional[List[Path]] = typer.Option(None, exists=True, dir_okay=False, resolve_path=True),
+    ontarget_labels: Optional[List[Path]] = typer.Option(None, exists=True, dir_okay=False, resolve_path=True),
+    offtarget_labels: Optional[List[Path]] = typer.Option(None, exists=True, dir_okay=False, resolve_path=True),
+    overwrite: bool = typer.Option(True, "--overwrite", "-w", help="Overwrite defaults values."),
+    no_input: bool = typer.Option(False, "--no-input", help="Accepted for compatibility (there are no prompts)."),
+    labels: bool = typer.Option(False, "--labels", "-l", help="Add on-target binding labels."),
+    progress_bar=None,
+):
+    """
+    Extract AOIs from raw glimpse images (tapqir/main.py:66-318) into ``<cd>/data.tpqr``.
+
+    Needs, per colour channel: the header/glimpse folder, the aoiinfo file of the target molecules (on-target AOIs),
+    optionally the aoiinfo file of the off-target control locations, and the driftlist file.  Values not given as flags
+    are taken from ``.tapqir/config.yaml`` (``channels: [{name, glimpse-folder, driftlist, ontarget-aoiinfo, ...}]``).
+    """
+    from tapqir_amd.exceptions import HipExtensionError
+    from tapqir_amd.imscroll import read_glimpse
+
+    cd = DEFAULTS["cd"]
+    logger = logging.getLogger("tapqir")
+    DEFAULTS.update({"dataset": dataset, "P": P, "offset-P": offset_P, "offset-x": offset_x, "offset-y": offset_y,
+                     "bin-size": bin_size, "frame-range": bool(frame_range), "frame-start": frame_start,
+                     "frame-end": frame_end, "use-offtarget": bool(use_offtarget), "num-channels": num_channels,
+                     "labels": labels})
+    flags = {"name": name, "glimpse-folder": glimpse_folder, "driftlist": driftlist, "ontarget-aoiinfo": ontarget_aoiinfo,
+             "offtarget-aoiinfo": offtarget_aoiinfo, "ontarget-labels": ontarget_labels, "offtarget-labels": offtarget_labels}
+    channels = [dict(ch) for ch in DEFAULTS.get("channels") or []]
+    for c in range(num_channels):
+        if len(channels) < c + 1:
+            channels.append({})
+        for key, values in flags.items():
+            if values and c < len(values):
+                channels[c][key] = str(values[c])
+        needed = ["name", "glimpse-folder", "driftlist", "ontarget-aoiinfo"] + (["offtarget-aoiinfo"] if use_offtarget else [])
+        missing = [key for key in needed if channels[c].get(key) is None]
+        if missing:
+            logger.error(f"Channel #{c}: missing {', '.join('--' + k for k in missing)} (flag or config.yaml)")
+            raise typer.Exit(1)
+        if labels:
+            channels[c].setdefault("ontarget-labels", None)
+            channels[c].setdefault("offtarget-labels", None)
+    DEFAULTS["channels"] = channels[:num_channels]
+    if overwrite:
+        _write_config(cd)
+
+    logger.info("Extracting AOIs ...")
+    try:
+        read_glimpse(path=cd, progress_bar=progress_bar, **{k: v for k, v in DEFAULTS.items() if k != "cd"})
+    except HipExtensionError:
+        logger.exception("Failed to extract AOIs: the extraction needs an AMD GPU and the built HIP library")
+        raise typer.Exit(1)
+    logger.info("Extracting AOIs: Done")
 
 
 @app.command()

@@ -42,10 +42,11 @@ def test_struct_sizes_match_the_c_header():
 #include <stddef.h>
 #include "tapqir_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tq_ksmogn_args), offsetof(tq_ksmogn_args, m_kstride),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tq_ksmogn_args), offsetof(tq_ksmogn_args, m_kstride),
          offsetof(tq_ksmogn_args, scale), sizeof(tq_cosmos_args), offsetof(tq_cosmos_args, Nt),
          offsetof(tq_cosmos_args, seed), sizeof(tq_xtalk_args), offsetof(tq_xtalk_args, m_kstride),
-         offsetof(tq_xtalk_args, scale), sizeof(tq_probs_args));
+         offsetof(tq_xtalk_args, scale), sizeof(tq_probs_args), sizeof(tq_glimpse_args),
+         offsetof(tq_glimpse_args, offset_P));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -56,7 +57,8 @@ int main(void) {
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     K, Cs, X = _lib.KsmognArgs, _lib.CosmosArgs, _lib.XtalkArgs
     want = [ctypes.sizeof(K), K.m_kstride.offset, K.scale.offset, ctypes.sizeof(Cs), Cs.Nt.offset, Cs.seed.offset,
-            ctypes.sizeof(X), X.m_kstride.offset, X.scale.offset, ctypes.sizeof(_lib.ProbsArgs)]
+            ctypes.sizeof(X), X.m_kstride.offset, X.scale.offset, ctypes.sizeof(_lib.ProbsArgs),
+            ctypes.sizeof(_lib.GlimpseArgs), _lib.GlimpseArgs.offset_P.offset]
     assert got == want
 
 

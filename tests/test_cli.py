@@ -59,3 +59,46 @@ def test_commands_cuda(dataset_path, model):
                                  "--fbatch-size", "5", "--cuda", "--matlab", "--no-input"])
     assert result.exit_code == 0, result.output
     assert (dataset_path / f"{model}_params.mat").is_file()
+
+
+def glimpse_cmd(path, cfg):
+    ch = cfg["channels"][0]
+    return ["--cd", str(path), "glimpse", "--dataset", "synthetic", "-P", str(cfg["P"]), "--offset-x", str(cfg["offset-x"]),
+            "--offset-y", str(cfg["offset-y"]), "--offset-P", str(cfg["offset-P"]), "--bin-size", "1", "--use-offtarget",
+            "-C", "1", "--name", ch["name"], "--glimpse-folder", ch["glimpse-folder"], "--driftlist", ch["driftlist"],
+            "--ontarget-aoiinfo", ch["ontarget-aoiinfo"], "--offtarget-aoiinfo", ch["offtarget-aoiinfo"], "--no-input"]
+
+
+def test_glimpse_command_needs_its_inputs_and_a_gpu(tmp_path):
+    """tapqir/main.py:66-318: without the per-channel files the command fails (exit 1); with them the extraction itself
+    needs the GPU (no CPU path) -- on a box without one that is exit 1 too, with the inputs recorded in config.yaml."""
+    import torch
+    from glimpse_fixture import write_experiment
+
+    assert runner.invoke(app, ["--cd", str(tmp_path), "glimpse", "--dataset", "x", "--no-input"]).exit_code == 1
+    cfg, _ = write_experiment(tmp_path / "raw", F=4, labels=False)
+    result = runner.invoke(app, glimpse_cmd(tmp_path, cfg))
+    saved = yaml.safe_load(open(tmp_path / ".tapqir" / "config.yaml"))
+    assert saved["channels"][0]["name"] == "dye0" and saved["offset-P"] == 20 and saved["use-offtarget"] is True
+    if not torch.cuda.is_available():
+        assert result.exit_code == 1 and "AMD GPU" in result.output
+
+
+@pytest.mark.gpu
+def test_glimpse_then_fit(tmp_path):
+    """Raw frames -> data.tpqr -> one SVI iteration, all through the command line."""
+    import torch
+    from glimpse_fixture import write_experiment
+    from oracle import glimpse as og
+
+    cfg, _ = write_experiment(tmp_path / "raw", F=6, labels=False)
+    result = runner.invoke(app, glimpse_cmd(tmp_path, cfg))
+    assert result.exit_code == 0, result.output
+    saved = torch.load(tmp_path / "data.tpqr", weights_only=False)
+    assert torch.equal(saved["images"], og.read_glimpse(**cfg)["images"])
+    result = runner.invoke(app, fit_cmd(tmp_path, "cosmos", "--cuda"))
+    assert result.exit_code == 0, result.output
+    assert (tmp_path / "cosmos_summary.csv").is_file()
+    # a second run picks the channel files up from config.yaml
+    result = runner.invoke(app, ["--cd", str(tmp_path), "glimpse", "--no-input"])
+    assert result.exit_code == 0, result.output
