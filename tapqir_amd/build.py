@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtapqir_hip.so")
 SOURCES = ["tq_ksmogn.hip", "tq_xtalk.hip", "tq_cosmos.hip", "tq_glimpse.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 
 
 def needs_build():
@@ -28,10 +28,22 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:  # one hipcc per translation unit, side by side
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+    for cmd, _, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [obj for _, obj, _ in jobs]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return OUT
 
 
