@@ -227,16 +227,20 @@ typedef struct {
   float lr, beta1, beta2, adam_eps;
   float bias_correction1, bias_correction2;  /* 1 - beta^t for this step */
   int32_t zero_grad;           /* 1: Adam clears grad after use (minibatch mode keeps grad dense-zero) */
-  int32_t fuse_adam;           /* 1 (full batch only): tq_cosmos_elbo_grads applies Adam to the local parameters of
-                                  each unit right where their gradient is formed (no gradient round trip through
-                                  HBM) and tq_cosmos_adam then updates only the per-AOI and global tail */
+  int32_t fuse_adam;           /* 1: tq_cosmos_elbo_grads applies Adam to the local parameters of each unit of the
+                                  batch right where their gradient is formed (no gradient round trip through HBM) and
+                                  tq_cosmos_adam then updates only the per-AOI and global tail.  Full batches, or
+                                  minibatches with `last_step` (lazy Adam, below) */
   int32_t crosstalk;           /* 1: the crosstalk model (tapqir/models/crosstalk.py; Q = C = 2, K <= 2): one data site per
                                   AOI-frame whose channel c sees every dye's spots scaled by alpha[q][c]; the global block
                                   of the parameter buffer grows by alpha_mean[Q][2], alpha_size[Q] (4+8Q entries), gsum
                                   by d/d alpha[q][c] (3+3Q+Q*Q entries) */
   /* RNG */
   uint64_t seed;
-  uint32_t step;
+  uint32_t step;               /* number of completed steps: Philox key of this step's draws; this step is Adam step `step + 1` */
+  /* lazy Adam of minibatch steps (tq_cosmos_adam_catchup) */
+  int32_t* last_step;          /* [Nt*F*C] Adam step at which the local parameters of a unit were last updated, or NULL */
+  double beta1_d, beta2_d;     /* the Adam betas in double: 1 - beta^s of the replayed steps is formed like the host's */
 } tq_cosmos_args;
 
 int64_t tq_globals_size(void);
@@ -260,6 +264,15 @@ int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream);
 int tq_cosmos_adam(const tq_cosmos_args* a, void* stream);
 /* all of the above back to back */
 int tq_cosmos_step(const tq_cosmos_args* a, void* stream);
+/* Lazy Adam for minibatch steps.  torch.optim.Adam updates EVERY element at every step; for the units outside the
+ * minibatch the gradient is zero and the update (m *= beta1, v *= beta2, p -= lr_s m / (sqrt(v / bc2_s) + eps)) depends on
+ * the element's own state and the step number only, so it can be replayed later from registers instead of streaming the
+ * whole parameter / moment buffers through HBM every step (28 B per element: 35 us at config c2, 1.1 ms at c3).
+ * tq_cosmos_adam_catchup replays, for every local parameter of the units of the batch (all_units = 0) or of the whole
+ * dataset (all_units = 1), the zero-gradient steps last_step[u] + 1 .. a->step.  A minibatch step with fuse_adam then
+ * runs it before its local sampling; tq_cosmos_elbo_grads applies step a->step + 1 and records it in last_step.  Call it
+ * with all_units = 1 before anything reads the buffers (it does not write last_step: the caller re-bases the clock). */
+int tq_cosmos_adam_catchup(const tq_cosmos_args* a, int32_t all_units, void* stream);
 /* Full-batch pipeline (fuse_adam steps).  The single-workgroup TAIL of a step -- cross-unit sums, global sites, total
  * ELBO, Adam of the per-AOI and global parameters (~35 us of latency on one CU) -- does not have to finish before the
  * NEXT step samples its local guide sites (they read local parameters only, already updated by the fused Adam).

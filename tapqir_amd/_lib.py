@@ -62,6 +62,7 @@ class CosmosArgs(C.Structure):
         ("bias_correction1", C.c_float), ("bias_correction2", C.c_float),
         ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32), ("crosstalk", C.c_int32),
         ("seed", C.c_uint64), ("step", C.c_uint32),
+        ("last_step", C.c_void_p), ("beta1_d", C.c_double), ("beta2_d", C.c_double),
     ]
 
 
@@ -114,7 +115,7 @@ EXPORTS = [
     "tq_interleaved_floats", "tq_interleaved_floats_n", "tq_images_interleave_n", "tq_images_interleave", "tq_image_stats",
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
+    "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
     "tq_cosmos_probs", "tq_glimpse_extract",
 ]
 
@@ -160,7 +161,7 @@ def load():
     lib.tq_ksmogn_log_prob.argtypes = [C.POINTER(KsmognArgs), C.c_void_p]
     lib.tq_ksmogn_log_prob.restype = C.c_int
     for name in ("tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_step", "tq_cosmos_tail"):
+                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_tail"):
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int
@@ -170,6 +171,8 @@ def load():
         fn.restype = C.c_int
     lib.tq_cosmos_sample_locals_range.argtypes = [C.POINTER(CosmosArgs), C.c_int32, C.c_int32, C.POINTER(CosmosArgs), C.c_void_p]
     lib.tq_cosmos_sample_locals_range.restype = C.c_int
+    lib.tq_cosmos_adam_catchup.argtypes = [C.POINTER(CosmosArgs), C.c_int32, C.c_void_p]
+    lib.tq_cosmos_adam_catchup.restype = C.c_int
     lib.tq_cosmos_probs.argtypes = [C.POINTER(ProbsArgs), C.c_void_p]
     lib.tq_cosmos_probs.restype = C.c_int
     lib.tq_glimpse_extract.argtypes = [C.POINTER(GlimpseArgs), C.c_void_p]

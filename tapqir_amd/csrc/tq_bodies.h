@@ -196,6 +196,7 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
 #pragma unroll
     for (int r = 0; r < NL; ++r)
       tq_adam_apply_given(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r], m_old[r], v_old[r]);
+    if (a.last_step) a.last_step[ix.u] = (int32_t)(a.step + 1);  // lazy Adam clock of the unit
   } else {
 #pragma unroll
     for (int r = 0; r < NL; ++r) a.grad[(int64_t)r * U + ix.u] = masked ? 0.0f : out.g[r];
@@ -262,6 +263,27 @@ TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, floa
   const float lr1 = a.lr * TQ_FRCP(a.bias_correction1);
   a.params[j] = p - lr1 * m * TQ_FRCP(TQ_FSQRT(v) * rs2 + a.adam_eps);
 }
+// Replay of the zero-gradient Adam steps s0..s1 of element j (lazy Adam of minibatch fits: the steps in which the
+// element's unit was not in the minibatch).  Same arithmetic as tq_adam_apply_given with g = 0; the bias corrections
+// 1 - beta^s are formed in double like the host's, with beta^s carried by multiplication.
+TQ_HD void tq_adam_replay(const tq_cosmos_args& a, int64_t j, int s0, int s1) {
+  if (s0 > s1) return;
+  float p = a.params[j], m = a.exp_avg[j], v = a.exp_avg_sq[j];
+  double pw1 = pow(a.beta1_d, (double)s0), pw2 = pow(a.beta2_d, (double)s0);
+  for (int s = s0; s <= s1; ++s) {
+    m = a.beta1 * m;
+    v = a.beta2 * v;
+    const float rs2 = TQ_FRCP(TQ_FSQRT((float)(1.0 - pw2)));
+    const float lr1 = a.lr * TQ_FRCP((float)(1.0 - pw1));
+    p = p - lr1 * m * TQ_FRCP(TQ_FSQRT(v) * rs2 + a.adam_eps);
+    pw1 *= a.beta1_d;
+    pw2 *= a.beta2_d;
+  }
+  a.params[j] = p;
+  a.exp_avg[j] = m;
+  a.exp_avg_sq[j] = v;
+}
+
 TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
   tq_adam_apply(a, j, a.params[j], a.grad[j]);
   if (a.zero_grad) a.grad[j] = 0.0f;

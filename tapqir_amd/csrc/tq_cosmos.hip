@@ -110,6 +110,14 @@ __global__ __launch_bounds__(256) void tq_adam_kernel(const tq_cosmos_args a, co
   for (int64_t j = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) tq_body_adam(a, j);
 }
 
+// lazy Adam: grid.x over the units of the batch (or of the dataset), grid.y = local parameter row
+__global__ __launch_bounds__(256) void tq_adam_catchup_kernel(const tq_cosmos_args a, const int64_t n, const int all_units) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t u = all_units ? i : tq_decode_unit(a, i).u;
+  tq_adam_replay(a, (int64_t)blockIdx.y * tq_num_units(a) + u, a.last_step[u] + 1, (int)a.step);
+}
+
 // single-GPU step: finish of the cross-unit sums + all global sites + total ELBO in ONE workgroup of 4 waves
 // (one wave per SIMD, so the fp64 site code keeps the full register file); sites are taken round-robin
 __device__ __forceinline__ double tq_wave_sum_d(double v) {
@@ -403,6 +411,18 @@ extern "C" int tq_cosmos_adam(const tq_cosmos_args* a, void* stream) {
   if (nblk > 256 * 16) nblk = 256 * 16;  // grid-stride: 16 workgroups per CU
   hipLaunchKernelGGL(tq_adam_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, *a, first, total);
   return check_launch("tq_adam_kernel");
+}
+
+extern "C" int tq_cosmos_adam_catchup(const tq_cosmos_args* a, int32_t all_units, void* stream) {
+  if (int rc = check_args(a, "adam_catchup")) return rc;
+  if (!a->last_step || !a->exp_avg || !a->exp_avg_sq) {
+    tq_set_error("tq_cosmos_adam_catchup: NULL required pointer (last_step, exp_avg, exp_avg_sq)");
+    return TQ_ERR_ARG;
+  }
+  const int64_t n = all_units ? tq_num_units(*a) : tq_batch_units(*a);
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)TQ_NLOCAL(a->K));
+  hipLaunchKernelGGL(tq_adam_catchup_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a, n, (int)all_units);
+  return check_launch("tq_adam_catchup_kernel");
 }
 
 // ---- whole steps ---------------------------------------------------------------------------------------------

@@ -114,7 +114,7 @@ class cosmos(Model):
         eng.exp_avg.zero_()
         eng.exp_avg_sq.zero_()
         eng.grad.zero_()
-        eng.adam_step = 0
+        eng.reset_adam_clock(0)
 
     # -- one SVI step ----------------------------------------------------------------------------------
     def _subsample(self):

@@ -61,7 +61,7 @@ class crosstalk(cosmos):
         eng.exp_avg.zero_()
         eng.exp_avg_sq.zero_()
         eng.grad.zero_()
-        eng.adam_step = 0
+        eng.reset_adam_clock(0)
 
     # -- posteriors (crosstalk.py:466-574) ------------------------------------------------------------------
     @property

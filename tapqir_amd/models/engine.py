@@ -102,10 +102,16 @@ class CosmosEngine:
                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tq_image_stats")
         self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps, crosstalk=self.layout_crosstalk)
         n = self.layout.total
-        self.params = torch.zeros(n, dtype=f32, device=dev)
+        self._params = torch.zeros(n, dtype=f32, device=dev)
         self.grad = torch.zeros(n, dtype=f32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
+        self._exp_avg = torch.zeros(n, dtype=f32, device=dev)
+        self._exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
+        # lazy Adam of minibatch steps (include/tapqir_hip.h: tq_cosmos_adam_catchup): per-unit clock of the last update;
+        # meaningful only while `_stale` (some unit's local parameters lag behind adam_step).  TAPQIR_AMD_LAZY_ADAM=0:
+        # every minibatch step streams the whole buffers through the dense Adam kernel instead
+        self.lazy_adam = (not self._hostcheck) and os.environ.get("TAPQIR_AMD_LAZY_ADAM", "1") != "0"
+        self._last_step = torch.zeros(self.Nt * self.F * self.C, dtype=torch.int32, device=dev)
+        self._stale = False
         gsz = int(lib.hc_globals_size() if self._hostcheck else lib.tq_globals_size())
         bsz = int(lib.hc_gbase_size() if self._hostcheck else lib.tq_gbase_size())
         self.globals = torch.zeros(gsz // 4, dtype=f32, device=dev)
@@ -126,6 +132,46 @@ class CosmosEngine:
         self.overlap_tail = os.environ.get("TAPQIR_AMD_OVERLAP", "1") != "0"
         self._tail_args = None  # arguments of the step whose tail is pending
 
+    # -- parameter / moment buffers ---------------------------------------------------------------
+    # Reading them from outside the step completes deferred work first: the pending tail of a pipelined step and the
+    # zero-gradient Adam steps that lazy minibatch steps still owe to the units outside their minibatches.
+    @property
+    def params(self):
+        self.join()
+        return self._params
+
+    @property
+    def exp_avg(self):
+        self.join()
+        return self._exp_avg
+
+    @property
+    def exp_avg_sq(self):
+        self.join()
+        return self._exp_avg_sq
+
+    def _catch_up_all(self):
+        """Bring the local parameters and moments of every unit to `adam_step` (lazy Adam)."""
+        if self._stale:
+            self._stale = False
+            a = _lib.CosmosArgs()  # only what the replay reads: buffers, geometry, optimiser constants, step count
+            p = _lib.ptr
+            a.params, a.exp_avg, a.exp_avg_sq, a.last_step = p(self._params), p(self._exp_avg), p(self._exp_avg_sq), p(self._last_step)
+            a.globals, a.gbase = p(self.globals), p(self.gbase)
+            a.Nt, a.F, a.C, a.P, a.K, a.O = self.Nt, self.F, self.C, self.P, self.K, self.O
+            a.nb, a.fb = self.Nt, self.F
+            a.lr, a.beta1, a.beta2, a.adam_eps = self.lr, self.betas[0], self.betas[1], self.adam_eps
+            a.beta1_d, a.beta2_d = float(self.betas[0]), float(self.betas[1])
+            a.crosstalk = int(self.crosstalk)
+            a.step = self.adam_step
+            _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), 1, self._stream()), "tq_cosmos_adam_catchup")
+
+    def reset_adam_clock(self, step=0):
+        """The buffers were (re)written from outside (initialisation, checkpoint): everything is current at `step`."""
+        self.join()
+        self.adam_step = int(step)
+        self._stale = False
+
     # -- workspace ---------------------------------------------------------------------------------
     def _workspace(self, nb, fb):
         key = (nb, fb)
@@ -143,15 +189,39 @@ class CosmosEngine:
         self.blk_part = torch.zeros(nblk * self.n_gsum, dtype=f32, device=dev)
         self._ws_key = key
 
+    def _index_to_device(self, idx, which):
+        """Subsample indices as a device int32 tensor.  Host tensors go through a small ring of pinned staging buffers
+        and an asynchronous copy: a pageable copy would block the host until the stream has drained, once per step."""
+        if idx.device.type == "cuda" or self.device.type != "cuda":
+            return idx.to(self.device, torch.int32).contiguous()
+        ring = self.__dict__.setdefault("_pin_ring", {})
+        if which not in ring:
+            n = max(self.Nt, self.F)
+            ring[which] = [[torch.empty(n, dtype=torch.int32).pin_memory(), torch.cuda.Event(), False] for _ in range(8)]
+        slots = ring[which]
+        k = self.__dict__.setdefault("_pin_count", [0, 0])
+        slot = slots[k[which] % len(slots)]
+        k[which] += 1
+        buf, ev, used = slot
+        if used:
+            ev.synchronize()  # the copy that last read this buffer (8 steps ago) has completed
+        n = idx.numel()
+        buf[:n].copy_(idx.reshape(-1))
+        out = buf[:n].to(self.device, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[2] = True
+        return out
+
     def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None):
         nb = self.Nt if ndx is None else int(ndx.numel())
         fb = self.F if fdx is None else int(fdx.numel())
         self._workspace(nb, fb)
         if ndx is not None:
-            ndx = ndx.to(self.device, torch.int32).contiguous()
+            ndx = self._index_to_device(ndx, 0)
         if fdx is not None:
-            fdx = fdx.to(self.device, torch.int32).contiguous()
-        self._keep = (ndx, fdx)  # keep index tensors alive while kernels run
+            fdx = self._index_to_device(fdx, 1)
+        # keep the index tensors alive while kernels run (the previous step's too: its tail may still be pending)
+        self._keep_prev, self._keep = getattr(self, "_keep", None), (ndx, fdx)
         p = _lib.ptr
         a = _lib.CosmosArgs()
         a.images, a.xy, a.is_ontarget, a.aoi_mask = p(self.images), p(self.xy), p(self.is_ontarget), p(self.mask)
@@ -159,7 +229,9 @@ class CosmosEngine:
         a.pixstats = p(self.pixstats)
         a.ndx, a.fdx = p(ndx), p(fdx)
         a.offset_samples, a.offset_logits = p(self.offset_samples), p(self.offset_logits)
-        a.params, a.grad, a.exp_avg, a.exp_avg_sq = p(self.params), p(self.grad), p(self.exp_avg), p(self.exp_avg_sq)
+        a.params, a.grad, a.exp_avg, a.exp_avg_sq = p(self._params), p(self.grad), p(self._exp_avg), p(self._exp_avg_sq)
+        a.last_step = p(self._last_step)
+        a.beta1_d, a.beta2_d = float(self.betas[0]), float(self.betas[1])
         a.lat, a.pix, a.aoi_part, a.blk_part = p(self.lat), p(self.pix), p(self.aoi_part), p(self.blk_part)
         a.site = p(self.site)
         a.draw_locals = int(bool(draw_globals if draw_locals is None else draw_locals))
@@ -186,6 +258,31 @@ class CosmosEngine:
         a.step = self.adam_step if step is None else int(step)
         return a
 
+    def _step_args(self, ndx, fdx):
+        """make_args for step(): the ~60 fields are filled once per batch geometry / optimiser setting and copied
+        afterwards; only the subsample pointers, the step count and the bias corrections change from step to step
+        (minibatch steps are launch-bound: the host side of a step must stay well below the ~50 us of its kernels)."""
+        nb = self.Nt if ndx is None else int(ndx.numel())
+        fb = self.F if fdx is None else int(fdx.numel())
+        key = (nb, fb, self.lr, self.betas, self.adam_eps, self.seed, id(self.priors), self._ws_key)
+        if self.__dict__.get("_tmpl_key") != key or self._ws_key != (nb, fb):
+            a = self.make_args(ndx, fdx)
+            self._tmpl, self._tmpl_key = _lib.CosmosArgs.from_buffer_copy(a), (nb, fb, self.lr, self.betas, self.adam_eps,
+                                                                              self.seed, id(self.priors), self._ws_key)
+            return a
+        a = _lib.CosmosArgs.from_buffer_copy(self._tmpl)
+        if ndx is not None:
+            ndx = self._index_to_device(ndx, 0)
+        if fdx is not None:
+            fdx = self._index_to_device(fdx, 1)
+        self._keep_prev, self._keep = self._keep, (ndx, fdx)
+        a.ndx, a.fdx = _lib.ptr(ndx), _lib.ptr(fdx)
+        t = self.adam_step + 1
+        a.bias_correction1 = 1.0 - self.betas[0] ** t
+        a.bias_correction2 = 1.0 - self.betas[1] ** t
+        a.step = self.adam_step
+        return a
+
     def _nb_global(self, nb):
         # AOI sharding: every rank subsamples nb local AOIs of Nt local ones, so the global
         # subsample is nb * (Nt_global / Nt)
@@ -209,8 +306,18 @@ class CosmosEngine:
         sites, Adam of the per-AOI and global parameters) is deferred: it runs after the NEXT step's local guide
         sampling, which needs local parameters only, so the collective's latency hides behind that kernel.  ``join()``
         (called by every read-out) completes a deferred tail."""
-        a = self.make_args(ndx, fdx)
-        a.fuse_adam = int(not a.zero_grad)  # full batch: Adam on the local block is fused into the unit kernel
+        a = self._step_args(ndx, fdx)
+        minibatch = bool(a.zero_grad)
+        # Adam on the local block is fused into the unit kernel: full batches, and minibatches with the lazy clock
+        a.fuse_adam = int(not minibatch or self.lazy_adam)
+        if minibatch and self.lazy_adam:
+            if not self._stale:
+                self._last_step.fill_(self.adam_step)  # every unit is current: start the clock here
+                self._stale = True
+            _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), 0, self._stream()), "tq_cosmos_adam_catchup")
+        else:
+            self._catch_up_all()
+            a.last_step = None  # full batch: no unit falls behind
         if allreduce is None and not self._hostcheck:
             self._finish_pending()
             if self.overlap_tail and a.fuse_adam:
@@ -283,6 +390,7 @@ class CosmosEngine:
         for its all-reduce.  Every read-out of elbo_out / parameters goes through here."""
         self._finish_pending()
         self._finish_tail()
+        self._catch_up_all()
 
     # -- named views -----------------------------------------------------------------------------------
     def named(self, which="params"):

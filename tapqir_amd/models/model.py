@@ -288,7 +288,7 @@ class Model:
                 m[n].copy_(st["exp_avg"].reshape(m[n].shape).to(eng.params.dtype))
                 v[n].copy_(st["exp_avg_sq"].reshape(v[n].shape).to(eng.params.dtype))
                 step = int(st["step"])
-            eng.adam_step = step
+            eng.reset_adam_clock(step)
             logger.info(f"Iteration #{self.iter}. Loaded a model checkpoint from {model_path}")
         if warnings and not checkpoint["convergence_status"]:
             logger.warning(f"Model at {path} has not been fully trained")
