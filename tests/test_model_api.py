@@ -174,5 +174,20 @@ def test_parallel_attach_single_rank_group(tmp_path):
             (tmp_path / ".tapqir" / "cosmos_model.tpqr").unlink()
         assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
         assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
+        # minibatch steps (lazy Adam + deferred tail behind the asynchronous all-reduce) against the plain fit
+        outs = []
+        for sharded in (False, True):
+            m = models["cosmos"](S=1, K=2, device="cuda", dtype="float")
+            m.load(tmp_path)
+            if sharded:
+                attach(m)
+            m.init(lr=0.005, nbatch_size=2, fbatch_size=3)
+            m.run(12, progress_bar=lambda x: x)
+            assert m.engine.lazy_adam
+            outs.append((m.engine.params.clone(), m.engine.exp_avg_sq.clone(), m.iter_loss))
+            (tmp_path / ".tapqir" / "cosmos_model.tpqr").unlink()
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-12)
+        assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
     finally:
         dist.destroy_process_group()
