@@ -59,5 +59,44 @@ def main():
                       "frac_of_8TBps": algo / ms / 1e6 / 8000, "outside": status[0].item()}))
 
 
+
+
+def end_to_end(H=512, W=512, F=300, n_on=400, n_off=200, P=14):
+    """Wall clock of read_glimpse (files -> data.tpqr) on a synthetic experiment, next to the oracle's frame loop on a
+    slice of it."""
+    import os
+    import sys
+    import tempfile
+    import time
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from glimpse_fixture import write_experiment
+    from oracle import glimpse as og
+    from tapqir_amd.imscroll import read_glimpse
+
+    with tempfile.TemporaryDirectory() as td:
+        cfg, _ = write_experiment(os.path.join(td, "raw"), H=H, W=W, F=F, n_on=n_on, n_off=n_off, P=P, kind="noisy", labels=False,
+                                  drift_scale=0.05, aoiinfo_frame=F // 2)
+        read_glimpse(td, None, **cfg)  # warm-up: library load, pinned buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ds = read_glimpse(td, None, **cfg)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        cfg_small = dict(cfg, **{"frame-range": True, "frame-start": F // 2 - 4, "frame-end": F // 2 + 5})
+        t0 = time.perf_counter()
+        og.read_glimpse(**cfg_small)
+        t_cpu = (time.perf_counter() - t0) * F / 10
+    units = (n_on + n_off) * F
+    print(json.dumps({"read_glimpse_s": t_gpu, "aoi_frames": units, "aoi_frames_per_s": units / t_gpu,
+                      "frame_MB": F * H * W * 2 / 1e6, "oracle_loop_s_extrapolated": t_cpu, "speedup": t_cpu / t_gpu,
+                      "images_shape": list(ds.images.shape)}))
+
+
 if __name__ == "__main__":
-    main()
+    import sys as _sys
+
+    if "--end-to-end" in _sys.argv:
+        end_to_end()
+    else:
+        main()
