@@ -635,30 +635,20 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
   // idle lanes of the last workgroup read the LAST tile too: the interleaved buffer ends with its 64-tile block
   const float4* src = reinterpret_cast<const float4*>(a.images_il) + ((i >> 6) * npix4) * 64 + (i & 63);
 
-  // every load of the unit is issued here, in one batch: the first pixel groups, the parameters and the data
-  // statistics the epilogue needs -- one memory round trip per wave instead of three dependent ones (with two waves
-  // per SIMD that start together, nothing else hides them)
-  float4 ring[G];
-#pragma unroll
-  for (int j = 0; j < G; ++j) ring[j] = src[j * 64];
   const float g = a.gain[0];
   const float rg = TQ_FRCP(g);
   const float ln_g = TQ_FLOG(g);
   const float off0 = a.offset_samples[0];
   const float tx = a.xy[2 * i], ty = a.xy[2 * i + 1];
   const float b = a.background[i];
-  const float S_v = a.pixstats[i];
-  const float S_lv = a.pixstats[a.stats_stride + i];
-  const bool bad = a.pixstats[2 * a.stats_stride + i] > 0.0f;
-  float amph[K], nl2[K], cx[K], cy[K], hk[K], wk[K];
+  float amph[K], nl2[K], cx[K], cy[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    hk[k] = a.height[k * B + i];
-    wk[k] = a.width[k * B + i];
+    const float hk = a.height[k * B + i], wk = a.width[k * B + i];
     cx[k] = a.x[k * B + i] + tx;
     cy[k] = a.y[k * B + i] + ty;
-    const float inv2v = 0.5f * TQ_FRCP(wk[k] * wk[k]);
-    amph[k] = hk[k] * inv2v * (1.0f / TQ_PI);
+    const float inv2v = 0.5f * TQ_FRCP(wk * wk);
+    amph[k] = hk * inv2v * (1.0f / TQ_PI);
     nl2[k] = -inv2v * 1.44269504088896340736f;
   }
   float W[M];
@@ -709,6 +699,9 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
       }
     }
 
+    float4 ring[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) ring[j] = src[j * 64];
     // one loop body = R rows; MORE: the groups of the next body are fetched as those of this one retire
     // (the last body is peeled so that the prefetches are unconditional and stay where they are written)
     auto run_body = [&](const int body, auto more_tag) {
@@ -729,19 +722,12 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
           const int pair = rr * (P / 2) + ip;  // pair index within the body (compile-time after unrolling)
           const int gi = pair >> 1;            // float4 group within the body
           const float4 d4 = ring[gi];
-          // v = D - delta is taken BEFORE the group is re-loaded: the old registers are dead at the load, which can
-          // then write the next body's group straight into them (no copy at the end of the body, whose wait would
-          // cover every load of the body: vmcnt(0) once per body)
-          const tq_f2 v = ((pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y}) - off0;
-          if (MORE && (pair & 1)) {
-            __builtin_amdgcn_sched_barrier(0);  // the load stays here, after the last use of the registers it writes
-            ring[gi] = nxt[gi * 64];
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          const tq_f2 D = (pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y};
+          if (MORE && (pair & 1)) ring[gi] = nxt[gi * 64];  // group consumed: fetch the next body's
           tq_f2 spot[K];
 #pragma unroll
           for (int k = 0; k < K; ++k) spot[k] = agy[k] * ex[k][ip];
-          tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c);
+          tq_pixel_pair<K, P, BWD, COLACC>(A, D - off0, b, spot, W, ip, ip == 0, c);
         }
         if (BWD) {
           // y-moments about the spot's own centre (the row offset dy is at hand): no cancellation later
@@ -770,9 +756,14 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
         tq_f2 s0 = A.S0[k], sx = A.Sx[k], sxx = A.Sxx[k];
         if (COLACC) {  // column sums folded with the column offsets from the spot's own centre
           s0 = sx = sxx = tq2(0.0f);
+          // the offsets are RE-computed from an opaque copy of the centre: shared with the prologue's (i - cx) and
+          // (i - cx)^2 they would stay live across the pixel loop, which at 256 registers means 64 B of scratch
+          // stores + loads per unit (PMC: +25 MB each way per launch)
+          float cxe = cx[k];
+          asm volatile("" : "+v"(cxe));
 #pragma unroll
           for (int ip = 0; ip < P / 2; ++ip) {
-            const tq_f2 dxc = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)} - cx[k];
+            const tq_f2 dxc = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)} - cxe;
             s0 += A.col[k][ip];
             sx += A.col[k][ip] * dxc;
             sxx += A.col[k][ip] * (dxc * dxc);
@@ -788,11 +779,16 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
     // some unit of this wave has a small alpha = background / gain: general (scalar, exact Binet) loop
     tq_il_pixel_loop<K, true, BWD, false>(S, a, src, P, npix, b, amph, nl2, cx, cy, g, rg, ln_g, W);
   }
+  const float S_v = a.pixstats[i];
+  const float S_lv = a.pixstats[a.stats_stride + i];
+  const bool bad = a.pixstats[2 * a.stats_stride + i] > 0.0f;
   tq_pixel_assemble_one_offset<K, BWD>(a, S, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
   if (live) {
-    float cxs[K], cys[K];
+    float hk[K], wk[K], cxs[K], cys[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+      hk[k] = a.height[k * B + i];
+      wk[k] = a.width[k * B + i];
       // reference points of the moments: the packed loop centres y on the spot and x on the spot (column sums) or on
       // the tile centre; the scalar fallback loop uses the tile centre for both
       cxs[k] = fastpath ? (COLACC ? 0.0f : cx[k] - 0.5f * (float)(P - 1)) : cx[k] - 0.5f * (float)(P - 1);
