@@ -212,7 +212,10 @@ class CosmosEngine:
         slot[2] = True
         return out
 
-    def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None):
+    def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None,
+                  _for_step=False):
+        if not _for_step:
+            self._catch_up_all()  # staged calls from outside read the parameters of arbitrary units
         nb = self.Nt if ndx is None else int(ndx.numel())
         fb = self.F if fdx is None else int(fdx.numel())
         self._workspace(nb, fb)
@@ -266,7 +269,7 @@ class CosmosEngine:
         fb = self.F if fdx is None else int(fdx.numel())
         key = (nb, fb, self.lr, self.betas, self.adam_eps, self.seed, id(self.priors), self._ws_key)
         if self.__dict__.get("_tmpl_key") != key or self._ws_key != (nb, fb):
-            a = self.make_args(ndx, fdx)
+            a = self.make_args(ndx, fdx, _for_step=True)
             self._tmpl, self._tmpl_key = _lib.CosmosArgs.from_buffer_copy(a), (nb, fb, self.lr, self.betas, self.adam_eps,
                                                                               self.seed, id(self.priors), self._ws_key)
             return a

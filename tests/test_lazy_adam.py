@@ -93,3 +93,23 @@ def test_model_minibatch_fit_and_checkpoint_round_trip(tmp_path):
     assert torch.equal(m2.engine.params, p1)
     m2.run(5, progress_bar=None)
     assert torch.isfinite(m2.engine.params).all()
+
+
+@pytest.mark.gpu
+def test_staged_calls_after_lazy_steps_see_current_parameters():
+    """make_args (used by TraceELBO.loss_and_grads and by staged test calls) completes the owed updates first."""
+    dense, lazy = engines()
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(6):
+        ndx, fdx = torch.randperm(6, generator=gen)[:2], torch.randperm(16, generator=gen)[:5]
+        for eng in (dense, lazy):
+            eng.step(ndx, fdx)
+    assert lazy._stale
+    out = []
+    for eng in (dense, lazy):
+        a = eng.make_args(torch.tensor([0, 3, 5]), torch.tensor([1, 2, 9, 15]))
+        for name in ("cosmos_sample_globals", "cosmos_sample_locals", "cosmos_elbo_grads", "cosmos_globals_grad"):
+            eng.call(name, a)
+        out.append(float(eng.elbo_out))
+    assert not lazy._stale
+    assert abs(out[0] - out[1]) <= 1e-5 * abs(out[0])
