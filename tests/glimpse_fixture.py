@@ -89,3 +89,35 @@ def write_experiment(root, H=64, W=72, F=12, n_on=5, n_off=3, C=1, P=14, seed=0,
            "frame-start": frame_range[0] if frame_range else None, "frame-end": frame_range[1] if frame_range else None,
            "use-offtarget": n_off > 0, "labels": labels}
     return cfg, truth
+
+
+def write_frames_experiment(root, frames, on_xy, off_xy, drift_dxdy, aoiinfo_frame, P, offset_x, offset_y, offset_P,
+                            name="sim"):
+    """One channel from explicit arrays: ``frames`` (F, H, W) counts 0..65535, AOI positions (0-based x, y) at the
+    aoiinfo frame, per-frame drift increments (F, 2) as (dx, dy) -> config dict for read_glimpse."""
+    os.makedirs(root, exist_ok=True)
+    F, H, W = frames.shape
+    with open(os.path.join(root, "0.glimpse"), "wb") as fid:
+        fid.write((frames - 2 ** 15).astype(">i2").tobytes())
+    savemat(os.path.join(root, "header.mat"), {"vid": {
+        "height": float(H), "width": float(W), "nframes": float(F), "filenumber": np.zeros(F, dtype=np.uint8),
+        "offset": (np.arange(F, dtype=np.uint64) * 2 * H * W).astype(np.uint32), "ttb": 100.0 * np.arange(F), "time1": 1.0}})
+    drift = np.zeros((F, 3))
+    drift[:, 0] = np.arange(1, F + 1)
+    drift[:, 1], drift[:, 2] = drift_dxdy[:, 1], drift_dxdy[:, 0]  # columns: frame, dy, dx
+    savemat(os.path.join(root, "driftlist.mat"), {"driftlist": drift})
+
+    def table(xy):
+        t = np.zeros((len(xy), 6))
+        t[:, 0], t[:, 1], t[:, 4] = aoiinfo_frame, 1, P
+        t[:, 3], t[:, 2] = xy[:, 0] + 1, xy[:, 1] + 1  # MATLAB coordinates
+        t[:, 5] = np.arange(1, len(xy) + 1)
+        return t
+
+    savemat(os.path.join(root, "on.mat"), {"aoiinfo2": table(on_xy)})
+    savemat(os.path.join(root, "off.mat"), {"aoiinfo2": table(off_xy)})
+    ch = {"name": name, "glimpse-folder": root, "driftlist": os.path.join(root, "driftlist.mat"),
+          "ontarget-aoiinfo": os.path.join(root, "on.mat"), "offtarget-aoiinfo": os.path.join(root, "off.mat")}
+    return {"P": P, "num-channels": 1, "dataset": name, "channels": [ch], "offset-P": offset_P, "offset-x": offset_x,
+            "offset-y": offset_y, "bin-size": 1, "frame-range": False, "frame-start": None, "frame-end": None,
+            "use-offtarget": True, "labels": False}

@@ -264,3 +264,51 @@ def test_read_glimpse_full_size_closed_form(tmp_path):
         og.count_offsets(analytic_frame(f, H, W), cfg["offset-x"], cfg["offset-y"], cfg["offset-P"], counts)
     s, w = og.finish_offsets(counts, int(want.min()), 1)
     assert torch.equal(ds.offset.samples.cpu(), s) and torch.equal(ds.offset.weights.cpu(), w)
+
+
+@pytest.mark.gpu
+def test_frames_to_fit(tmp_path):
+    """Whole input side feeding the hot path: simulated AOI images are painted into drifting full frames, extracted with
+    read_glimpse (GPU), and the fit of the extracted data.tpqr recovers the simulated binding labels."""
+    import math
+
+    from glimpse_fixture import write_frames_experiment
+    from tapqir_amd.models import models
+    from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+    N, F, P = 16, 150, 14
+    sim = simulate(2, N, F, 1, P, seed=4, params=TEST_PARAMS)
+    rng = np.random.default_rng(0)
+    H = W = 160
+    step = rng.integers(-1, 2, size=(F, 2))  # integer stage drift per frame
+    ref = 40  # aoiinfo frame (1-based): its own drift entry stays raw, so it is zero here
+    step[ref - 1] = 0
+    cum = og.cumulative_drift(np.arange(1, F + 1), step.astype(float), ref)
+    assert np.abs(cum).max() < 18
+    # AOI corners on a grid with room for the drift; the target sits at the window centre (P - 1) / 2 like the simulation
+    gx, gy = np.meshgrid(np.arange(4), np.arange(4))
+    corner = np.stack([30 + 32 * gx.ravel(), 30 + 32 * gy.ravel()], -1)[:N]
+    centre = corner + 0.5 * (P - 1)
+    frames = rng.integers(88, 93, size=(F, H, W)).astype(np.int64)  # camera offset ~ 90 everywhere else
+    imgs = sim.images[:, :, 0].numpy().astype(np.int64)
+    for f in range(F):
+        for n in range(N):
+            sx, sy = int(corner[n, 0] + cum[f, 0]), int(corner[n, 1] + cum[f, 1])
+            frames[f, sy:sy + P, sx:sx + P] = imgs[n, f]
+    cfg = write_frames_experiment(str(tmp_path / "raw"), frames, centre[: N // 2], centre[N // 2:], step.astype(float), ref, P,
+                                  offset_x=0, offset_y=0, offset_P=10)
+    ds = read_glimpse(tmp_path, None, **cfg)
+    assert torch.equal(ds.images[:, :, 0], torch.from_numpy(imgs))  # the painted tiles come back bit for bit
+    assert torch.equal(ds.xy, torch.full((N, F, 1, 2), 0.5 * (P - 1), dtype=torch.float64))
+    assert ds.is_ontarget.tolist() == [True] * (N // 2) + [False] * (N // 2)
+    assert 86 <= int(ds.offset.samples.min()) and int(ds.offset.samples.max()) <= 92
+
+    m = models["cosmos"](S=1, K=2, device="cuda", dtype="float")
+    m.load(tmp_path)
+    m.init(lr=0.005, nbatch_size=N, fbatch_size=F)
+    m.run(2500, progress_bar=lambda x: x)
+    z = m.z_probs[: N // 2, :, 0, 1].cpu() > 0.5
+    truth = torch.as_tensor(sim.labels["z"][:, :, 0]).bool()
+    tp, tn = float((z & truth).sum()), float((~z & ~truth).sum())
+    fp, fn = float((z & ~truth).sum()), float((~z & truth).sum())
+    assert (tp * tn - fp * fn) / math.sqrt((tp + fp) * (tp + fn) * (tn + fp) * (tn + fn)) > 0.9
