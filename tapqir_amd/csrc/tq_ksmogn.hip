@@ -629,6 +629,7 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
   constexpr int NB = P / R;                 // bodies per tile
   constexpr int npix = P * P, npix4 = npix / 4;
   constexpr bool COLACC = BWD && (K * P <= 28);
+  constexpr bool PINNED = BWD && K == 2;  // prefetches fenced in place + first body peeled (see run_body)
   const int64_t i_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;  // one wave per workgroup: no barriers, finest dispatch granularity
   const bool live = i_raw < B;
   const int64_t i = live ? i_raw : (B - 1);
@@ -722,12 +723,24 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
           const int pair = rr * (P / 2) + ip;  // pair index within the body (compile-time after unrolling)
           const int gi = pair >> 1;            // float4 group within the body
           const float4 d4 = ring[gi];
-          const tq_f2 D = (pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y};
-          if (MORE && (pair & 1)) ring[gi] = nxt[gi * 64];  // group consumed: fetch the next body's
+          // v = D - delta is taken BEFORE the group is re-loaded, and (backward kernel) the load is fenced in place:
+          // the old registers are dead at the load, which writes the next body's group straight into them.  A refill
+          // hoisted above the last use of its registers costs a copy at the end of the body, and that copy waits for
+          // every load of the body (vmcnt(0) once per body, ~1 us each).  Together with the peeled first body (the
+          // loop is then entered with the loads pending in the same order as at its back edge, so the waits the
+          // compiler derives are exact: vmcnt(6) before each group) this is worth 1-8 % of the K = 2 backward launch,
+          // depending on the box; the forward kernels do not profit and the K = 1 backward kernel would lose its
+          // fourth wave per SIMD (130 registers), so they keep the plain form (PINNED).
+          const tq_f2 v = ((pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y}) - off0;
+          if (MORE && (pair & 1)) {
+            if (PINNED) __builtin_amdgcn_sched_barrier(0);
+            ring[gi] = nxt[gi * 64];
+            if (PINNED) __builtin_amdgcn_sched_barrier(0);
+          }
           tq_f2 spot[K];
 #pragma unroll
           for (int k = 0; k < K; ++k) spot[k] = agy[k] * ex[k][ip];
-          tq_pixel_pair<K, P, BWD, COLACC>(A, D - off0, b, spot, W, ip, ip == 0, c);
+          tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c);
         }
         if (BWD) {
           // y-moments about the spot's own centre (the row offset dy is at hand): no cancellation later
@@ -740,8 +753,14 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
         }
       }
     };
+    if (PINNED) {  // first body peeled: see above
+      run_body(0, std::true_type{});
 #pragma unroll 1
-    for (int body = 0; body < NB - 1; ++body) run_body(body, std::true_type{});
+      for (int body = 1; body < NB - 1; ++body) run_body(body, std::true_type{});
+    } else {
+#pragma unroll 1
+      for (int body = 0; body < NB - 1; ++body) run_body(body, std::true_type{});
+    }
     run_body(NB - 1, std::false_type{});
 
     // fold the two pixel slots, then the common single-offset assembly / store
