@@ -252,11 +252,20 @@ def main():
     eng.join()
     elbo = float(eng.elbo_out[0])
     assert torch.isfinite(eng.params).all(), "non-finite parameters after the timed steps"
+    # host side of a step (outside the timed region): time to ENQUEUE 20 steps on an idle queue; if it approaches
+    # ms_per_step the launch path, not the GPU, sets the pace
+    barrier()
+    th = time.perf_counter()
+    for _ in range(20):
+        eng.step(allreduce=allreduce)
+    host_ms = (time.perf_counter() - th) / 20 * 1e3
+    eng.join()
+    barrier()
 
     out = {
         "metric": f"{args.model} SVI AOI-frames/s (= ELBO steps/s x nb x fb), K=2 P=14 full batch",
         "value": value, "unit": "AOI-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": host_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} K={K}, {N} AOIs x {F} frames x {Cc} channel(s) per GPU, P={P}, full-batch SVI step "
                                f"(sample guide, ELBO, gradients, dense Adam); offsets={args.offsets} (O={eng.O} after merging)",
