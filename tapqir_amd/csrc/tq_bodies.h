@@ -82,8 +82,8 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
     const int rl = site == 0 ? TQ_ROW_BLOC(K) : TQ_ROW(TQ_P_HLOC, site - 1, K);
     const int rb = site == 0 ? TQ_ROW_BBETA(K) : TQ_ROW(TQ_P_HBETA, site - 1, K);
     const float ul = P[rl * U + ix.u], ub = P[rb * U + ix.u];
-    const float loc = expf(ul), beta = expf(ub);
-    if (a.draw_locals) val = fmaxf(tq_sample_std_gamma(&s, loc * beta) / beta, tiny);
+    const float loc = TQ_FEXP(ul), beta = TQ_FEXP(ub);
+    if (a.draw_locals) val = fmaxf(tq_sample_std_gamma(&s, loc * beta) * TQ_FRCP(beta), tiny);
     tq_gamma_site_terms(val, loc, beta, terms);
   } else {  // AffineBeta
     const int j = site - 1 - K;
@@ -101,11 +101,12 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
     }
     const float sc = hi - lo;
     const float mean = (lo + a.eps) + (sc - 2.0f * a.eps) * tq_sigmoid(um);
-    const float size = 2.0f + expf(us);
+    const float size = 2.0f + TQ_FEXP(us);
     if (a.draw_locals) {
-      const float c1 = size * (mean - lo) / sc, c0 = size * (hi - mean) / sc;
+      const float rsc = TQ_FRCP(sc);
+      const float c1 = size * (mean - lo) * rsc, c0 = size * (hi - mean) * rsc;
       const float g1 = tq_sample_std_gamma(&s, c1), g0 = tq_sample_std_gamma(&s, c0);
-      float tt = g1 / (g1 + g0);
+      float tt = g1 * TQ_FRCP(g1 + g0);
       tt = fminf(fmaxf(tt, tiny), 1.0f - 5.96046448e-08f);  // torch._sample_dirichlet clamp
       val = fminf(fmaxf(lo + sc * tt, lo + a.eps * sc), hi - a.eps * sc);  // pyro AffineBeta.rsample clamp
     }

@@ -247,20 +247,21 @@ TQ_HD void tq_binet(float a, float lna, float ra, float* S, float* dS) {
     tq_binet_series<float>(a, ra, S, dS);
     return;
   }
-  // slow path (rare on the pixel path: needs background/gain < 8)
+  // shifted path: rare on the pixel path (needs background/gain < 8), the rule for the height sites of the guide
+  // (concentration ~2), hence the hardware reciprocals / logarithms
   float prod = 1.0f, rsum = 0.0f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float ai = a + (float)i;
     prod *= ai;
-    rsum += 1.0f / ai;
+    rsum += TQ_FRCP(ai);
   }
   const float b = a + 8.0f;
-  const float lnb = logf(b), rb = 1.0f / b;
+  const float lnb = TQ_FLOG(b), rb = TQ_FRCP(b);
   float Sb, dSb;
   tq_binet_series<float>(b, rb, &Sb, &dSb);
   // lgamma(a) = (b-1/2)ln b - b + c + Sb - ln prod  and  S(a) = lgamma(a) - (a-1/2)ln a + a - c
-  *S = (b - 0.5f) * lnb - 8.0f + Sb - logf(prod) - (a - 0.5f) * lna;
+  *S = (b - 0.5f) * lnb - 8.0f + Sb - TQ_FLOG(prod) - (a - 0.5f) * lna;
   // digamma(a) = ln b - 1/(2b) + dSb - rsum ; S'(a) = digamma(a) - ln a + 1/(2a)
   *dS = (lnb - lna) - 0.5f * rb + dSb - rsum + 0.5f * ra;
 }

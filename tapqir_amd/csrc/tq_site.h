@@ -58,6 +58,12 @@ struct TqSiteConsts {
   float bg_mean_std, bg_std_std;  // only used by the AOI kernel
 };
 
+// ln(1 + u) with the rounding of 1 + u compensated (|u| < 1/2): one hardware log, one reciprocal
+TQ_HD float tq_log1p_small(float u) {
+  const float w = 1.0f + u;
+  return TQ_FLOG(w) - ((w - 1.0f) - u) * TQ_FRCP(w);
+}
+
 // ---- log-densities with derivatives ---------------------------------------------------------------
 // Gamma(v; alpha = loc*beta, rate = beta) in the cancellation-free form (see tq_pixel.h):
 //   = -ln v + alpha phi(v/loc) + (1/2) ln alpha - ln sqrt(2pi) - S(alpha)
@@ -68,7 +74,7 @@ TQ_HD void tq_gamma_logpdf(float v, float loc, float beta, float* lp, float* d_v
   const float lnv = TQ_FLOG(v);
   // ln(v / loc): log1p near the mean (no cancellation in phi), difference of logs far from it (a draw many orders of
   // magnitude below loc, as Gamma draws with concentration < 1 are, must not round (v - loc) / loc to -1)
-  const float lrho = (fabsf(v - loc) < 0.5f * loc) ? log1pf((v - loc) * rloc) : lnv - TQ_FLOG(loc);
+  const float lrho = (fabsf(v - loc) < 0.5f * loc) ? tq_log1p_small((v - loc) * rloc) : lnv - TQ_FLOG(loc);
   const float lna = TQ_FLOG(alpha), ra = TQ_FRCP(alpha);
   float S, dS;
   tq_binet(alpha, lna, ra, &S, &dS);
@@ -76,12 +82,6 @@ TQ_HD void tq_gamma_logpdf(float v, float loc, float beta, float* lp, float* d_v
   *d_v = (alpha - 1.0f) * TQ_FRCP(v) - beta;
   *d_alpha = lrho + 0.5f * ra - dS;  // = ln beta + ln v - digamma(alpha)
   *d_beta = loc - v;                 // = alpha / beta - v
-}
-
-// ln(1 + u) with the rounding of 1 + u compensated (|u| < 1/2): one hardware log, one reciprocal
-TQ_HD float tq_log1p_small(float u) {
-  const float w = 1.0f + u;
-  return TQ_FLOG(w) - ((w - 1.0f) - u) * TQ_FRCP(w);
 }
 
 // Beta(t; c1, c0)
