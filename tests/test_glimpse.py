@@ -312,3 +312,14 @@ def test_frames_to_fit(tmp_path):
     tp, tn = float((z & truth).sum()), float((~z & ~truth).sum())
     fp, fn = float((z & ~truth).sum()), float((~z & truth).sum())
     assert (tp * tn - fp * fn) / math.sqrt((tp + fp) * (tp + fn) * (tn + fp) * (tn + fn)) > 0.9
+
+
+@pytest.mark.gpu
+def test_read_glimpse_more_aois_than_one_launch_covers(tmp_path):
+    """70 000 AOIs: tq_glimpse_extract takes at most 65 535 per call (grid.y), the host splits the rest off."""
+    cfg, _ = write_experiment(tmp_path / "raw", F=2, n_on=40000, n_off=30000, P=6, labels=False, aoiinfo_frame=1, seed=9)
+    ds = read_glimpse(tmp_path, None, **cfg)
+    want = og.read_glimpse(**cfg)
+    assert ds.images.shape == (70000, 2, 1, 6, 6)
+    assert torch.equal(ds.images, want["images"]) and torch.equal(ds.xy, want["xy"])
+    assert torch.equal(ds.offset.samples.cpu(), want["offset_samples"]) and torch.equal(ds.offset.weights.cpu(), want["offset_weights"])
