@@ -208,7 +208,7 @@ class CosmosEngine:
         n = idx.numel()
         buf[:n].copy_(idx.reshape(-1))
         out = buf[:n].to(self.device, non_blocking=True)
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record()  # on the current stream
         slot[2] = True
         return out
 
@@ -293,7 +293,12 @@ class CosmosEngine:
 
     # -- launches ------------------------------------------------------------------------------------
     def _stream(self):
-        return None if self._hostcheck else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self._hostcheck:
+            return None
+        # the raw handle of torch's current stream (torch.cuda.current_stream() builds a Stream object: ~9 us a call,
+        # several calls per step)
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(index))
 
     def call(self, name, args):
         if self._hostcheck:

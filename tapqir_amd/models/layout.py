@@ -89,9 +89,11 @@ class ParamLayout:
             cons["alpha_size"] = c.positive
         return cons
 
-    def constrained(self, flat):
+    def constrained(self, flat, names=None):
+        """dict name -> constrained value; ``names`` restricts it (the convergence check of every checkpoint needs
+        the few global parameters, not the transform of every local one)."""
         cons = self.constraints()
-        return {n: transform_to(cons[n])(v) for n, v in self.views(flat).items()}
+        return {n: transform_to(cons[n])(v) for n, v in self.views(flat).items() if names is None or n in names}
 
     def set_constrained(self, flat, values):
         """Write constrained values (dict name -> tensor) as unconstrained leaves (pyro.param

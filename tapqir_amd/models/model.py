@@ -198,7 +198,8 @@ class Model:
             for k, v in self.named_params().items():
                 if not bool(torch.isfinite(v).all()):
                     raise ValueError("Iteration #{}. Detected NaN values in {}".format(self.iter, k))
-        cparams = eng.layout.constrained(eng.params)
+        # (without a tensorboard writer only the convergence parameters -- globals -- are needed)
+        cparams = eng.layout.constrained(eng.params, None if writer is not None else set(self.conv_params))
         for name in self.conv_params:
             if name == "-ELBO":
                 self._rolling["-ELBO"].append(self.iter_loss)
@@ -242,20 +243,21 @@ class Model:
     def _param_store_state(self):
         """Same payload shape as pyro.get_param_store().get_state()."""
         cons = self.engine.layout.constraints()
-        return {
-            "params": {n: v.detach().cpu().clone() for n, v in self.named_params().items()},
-            "constraints": {n: cons[n] for n in self.named_params()},
-        }
+        # ONE download of the flat buffer; the entries are views of the host copy (a fit at the default minibatch makes
+        # a step in 0.08 ms: 200 separate device-to-host copies + clones per checkpoint cost more than the 200 steps
+        # between two checkpoints)
+        host = self.engine.layout.views(self.engine.params.detach().cpu())
+        return {"params": dict(host), "constraints": {n: cons[n] for n in host}}
 
     def _optim_state(self):
         """Same payload shape as pyro.optim.PyroOptim.get_state(): name -> torch Adam state_dict."""
         eng = self.engine
-        m, v = eng.named("exp_avg"), eng.named("exp_avg_sq")
+        m = eng.layout.views(eng.exp_avg.detach().cpu())
+        v = eng.layout.views(eng.exp_avg_sq.detach().cpu())
         out = {}
         for n in m:
             out[n] = {
-                "state": {0: {"step": torch.tensor(float(eng.adam_step)), "exp_avg": m[n].detach().cpu().clone(),
-                              "exp_avg_sq": v[n].detach().cpu().clone()}},
+                "state": {0: {"step": torch.tensor(float(eng.adam_step)), "exp_avg": m[n], "exp_avg_sq": v[n]}},
                 "param_groups": [{"lr": eng.lr, "betas": tuple(eng.betas), "eps": eng.adam_eps, "weight_decay": 0,
                                   "amsgrad": False, "maximize": False, "params": [0]}],
             }
