@@ -1,36 +1,43 @@
 """
-Exceptions of the drop-in surface (mirrors tapqir/exceptions.py:9-39: same names,
-same constructor arguments, same messages).
+Exception types of the drop-in surface.  Names, constructor arguments and message texts are the interface of
+tapqir/exceptions.py:9-39 (callers match on them: ``main.fit`` logs ``err.name``; ``Model.run`` converts a device
+out-of-memory RuntimeError into ``CudaOutOfMemoryError``); ``HipExtensionError`` is this build's own.
 """
 
-from pathlib import Path
+import os
 from typing import Union
+
+PathLike = Union[str, "os.PathLike[str]"]
 
 
 class TapqirException(Exception):
-    """Base class of all tapqir exceptions."""
+    """Root of the package's exceptions; ``msg`` keeps the text for callers that log it."""
 
-    def __init__(self, msg, *args):
-        assert msg
+    def __init__(self, msg, *extra):
+        if not msg:
+            raise AssertionError("a TapqirException needs a message")
+        super().__init__(msg, *extra)
         self.msg = msg
-        super().__init__(msg, *args)
 
 
 class TapqirFileNotFoundError(TapqirException):
-    """A data / parameter / summary / model file is missing."""
+    """A file of the workspace (``name`` = "data", "params", "summary", "model" ...) is not where it should be."""
 
-    def __init__(self, name: str, path: Union[str, Path]):
-        self.name = name
-        self.path = path
-        super().__init__(f"Unable to find {name} file '{path}'")
+    MESSAGE = "Unable to find {name} file '{path}'"
+
+    def __init__(self, name: str, path: PathLike):
+        super().__init__(self.MESSAGE.format(name=name, path=path))
+        self.name, self.path = name, path
 
 
 class CudaOutOfMemoryError(TapqirException):
-    """Device memory exhausted (the ROCm runtime words it "HIP out of memory")."""
+    """Device memory is exhausted (the ROCm runtime words it "HIP out of memory")."""
+
+    MESSAGE = "CUDA out of memory. Try to use smaller AOI/frame batch size"
 
     def __init__(self):
-        super().__init__("CUDA out of memory. Try to use smaller AOI/frame batch size")
+        super().__init__(self.MESSAGE)
 
 
 class HipExtensionError(TapqirException):
-    """The hand-written HIP library is missing or failed: there is NO fallback path."""
+    """libtapqir_hip.so is missing, failed to load or returned an error: the HIP path has NO fallback."""

@@ -63,20 +63,19 @@ def _aoi_table(path):
 
 class GlimpseDataset:
     """
-    Parses header, aoiinfo, driftlist and (optionally) intervals files (glimpse_reader.py:41-164).
+    Metadata of one colour channel of a Glimpse / imscroll experiment (interface of glimpse_reader.py:41-164).
 
-    :param name: Channel name.
-    :param glimpse-folder: Path to the header/glimpse folder.
-    :param ontarget-aoiinfo: Path to the on-target AOI locations file.
-    :param offtarget-aoiinfo: Path to the off-target control AOI locations file (optional).
-    :param driftlist: Path to the driftlist file.
-    :param frame-start: First frame to include in the analysis (optional).
-    :param frame-end: Last frame to include in the analysis (optional).
-    :param ontarget-labels: Path to the on-target label intervals file.
+    Keyword arguments are the per-channel entries of ``.tapqir/config.yaml`` merged with the command's options:
+    ``name`` (label of the channel), ``glimpse-folder`` (directory holding ``header.mat`` and the ``N.glimpse`` frame
+    files), ``driftlist`` (stage drift per frame), ``ontarget-aoiinfo`` / ``offtarget-aoiinfo`` (AOI positions: MATLAB
+    file or text table; the second only with ``use-offtarget``), ``frame-range`` with ``frame-start`` / ``frame-end``
+    (restrict the analysis to these frames, inclusive), ``labels`` with ``ontarget-labels`` / ``offtarget-labels``
+    (spot-picker interval files), ``offset-x`` / ``offset-y`` (corner of the dark region used for the camera offset).
 
-    Attributes as in the reference: ``header`` (dict), ``aoiinfo[dtype]`` (DataFrame indexed by aoi number with
-    0-based x, y), ``cumdrift`` (DataFrame indexed by frame: dx, dy accumulated relative to the aoiinfo frame, ttb),
-    ``labels[dtype]``, ``dtypes``, ``height``, ``width``, ``N``, ``Nc``, ``F``.
+    Attributes, named as in the reference: ``header`` (dict of the ``vid`` struct), ``aoiinfo[dtype]`` (DataFrame indexed
+    by AOI number, x / y converted to 0-based pixels), ``cumdrift`` (DataFrame indexed by frame number: dx, dy summed
+    relative to the frame the AOIs were picked in, ttb), ``labels[dtype]``, ``dtypes``, ``height``, ``width``, ``N``,
+    ``Nc``, ``F``.
     """
 
     def __init__(self, c=0, **kwargs):

@@ -1,161 +1,142 @@
 """
 Dataset container and ``data.tpqr`` file format of the drop-in surface.
 
-Mirrors tapqir/utils/dataset.py:18-222 (``OffsetData``, ``CosmosDataset``, ``save``,
-``load``): same attribute names, same dict keys in the file, so a ``data.tpqr`` written by
-the reference loads here and vice versa.  ``Vindex`` is replaced by plain advanced
-indexing (the only use, ``fetch``, indexes with broadcastable index tensors).
+Public surface of tapqir/utils/dataset.py:18-222 -- ``OffsetData`` (samples, weights + min / max / logits / mean /
+var), ``CosmosDataset`` (images, xy, is_ontarget, mask, labels, offset, time1, ttb, name, channels; sizes N, Nc, Nt,
+F, C, P; x, y, median, vmin, vmax, fetch), ``save`` and ``load`` with the file's dict keys unchanged -- so a
+``data.tpqr`` written by the reference loads here and vice versa.  ``fetch`` uses plain advanced indexing (its index
+tensors are broadcastable; no ``Vindex`` needed).
 """
 
 import logging
-from collections import namedtuple
 from pathlib import Path
+from typing import NamedTuple
 
 import torch
-from torch.distributions.utils import lazy_property, probs_to_logits
+from torch.distributions.utils import probs_to_logits
 
 from tapqir_amd.exceptions import TapqirFileNotFoundError
 
 logger = logging.getLogger(__name__)
 
+DATA_FILE = "data.tpqr"
+# keys of the saved dict, in file order (dataset.py:195-212)
+FILE_KEYS = ("images", "xy", "is_ontarget", "mask", "labels", "offset_samples", "offset_weights", "name", "time1", "ttb",
+             "channels")
 
-class OffsetData(namedtuple("OffsetData", ["samples", "weights"])):
-    """Empirical camera-offset distribution (dataset.py:18-37)."""
 
-    @lazy_property
+class OffsetData(NamedTuple):
+    """Empirical camera-offset distribution: support points and their probabilities (dataset.py:18-37)."""
+
+    samples: torch.Tensor
+    weights: torch.Tensor
+
+    def _moment(self, power):
+        return float((self.samples ** power * self.weights).sum())
+
+    @property
     def min(self):
-        return torch.min(self.samples).item()
+        return self.samples.min().item()
 
-    @lazy_property
+    @property
     def max(self):
-        return torch.max(self.samples).item()
+        return self.samples.max().item()
 
-    @lazy_property
+    @property
     def logits(self):
         return probs_to_logits(self.weights)
 
-    @lazy_property
+    @property
     def mean(self):
-        return torch.sum(self.samples * self.weights).item()
+        return self._moment(1)
 
-    @lazy_property
+    @property
     def var(self):
-        return torch.sum(self.samples**2 * self.weights).item() - self.mean**2
+        return self._moment(2) - self._moment(1) ** 2
 
 
 class CosmosDataset:
-    """images (Nt,F,C,P,P), xy (Nt,F,C,2), is_ontarget (Nt,), mask (Nt,), labels, offset
-    (dataset.py:40-192)."""
+    """AOI images ``(Nt, F, C, P, P)`` with target positions ``xy (Nt, F, C, 2)``, the on-target flag and fit mask per
+    AOI, optional labels and acquisition times, and the offset distribution (dataset.py:40-192)."""
 
-    def __init__(self, images, xy, is_ontarget, mask=None, labels=None, offset_samples=None,
-                 offset_weights=None, device=torch.device("cpu"), time1=None, ttb=None,
-                 name=None, channels=None):
-        self.images = images
-        self.xy = xy
-        self.is_ontarget = is_ontarget
-        if mask is None:
-            mask = torch.ones_like(is_ontarget, dtype=torch.bool)
-        self.mask = mask
-        self.labels = labels
+    def __init__(self, images, xy, is_ontarget, mask=None, labels=None, offset_samples=None, offset_weights=None,
+                 device=torch.device("cpu"), time1=None, ttb=None, name=None, channels=None):
+        self.images, self.xy, self.is_ontarget = images, xy, is_ontarget
+        self.mask = torch.ones_like(is_ontarget, dtype=torch.bool) if mask is None else mask
+        self.labels, self.time1, self.ttb, self.name = labels, time1, ttb, name
         self.device = device
         self.offset = OffsetData(offset_samples.to(device), offset_weights.to(device))
-        self.time1 = time1
-        self.ttb = ttb
-        self.name = name
-        if channels is None:
-            channels = tuple(f"channel{c}" for c in range(self.C))
-        self.channels = channels
+        self.channels = tuple(f"channel{c}" for c in range(images.shape[2])) if channels is None else channels
+        if images.shape[3] != images.shape[4]:
+            raise ValueError(f"AOI images must be square, got {tuple(images.shape[3:5])}")
+        self._cache = {}
 
-    @lazy_property
-    def N(self) -> int:
-        return int(self.is_ontarget.sum().item())
+    # -- sizes ----------------------------------------------------------------------------------------------
+    def _cached(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
 
-    @lazy_property
-    def Nc(self) -> int:
-        return int((~self.is_ontarget).sum().item())
+    N = property(lambda self: self._cached("N", lambda: int(self.is_ontarget.sum())), doc="number of on-target AOIs")
+    Nc = property(lambda self: self._cached("Nc", lambda: int((~self.is_ontarget).sum())), doc="number of off-target AOIs")
+    Nt = property(lambda self: self.N + self.Nc, doc="total number of AOIs")
+    F = property(lambda self: self.images.shape[1], doc="number of frames")
+    C = property(lambda self: self.images.shape[2], doc="number of colour channels")
+    P = property(lambda self: self.images.shape[3], doc="AOI side in pixels")
+    x = property(lambda self: self.xy[..., 0], doc="target position along the column axis")
+    y = property(lambda self: self.xy[..., 1], doc="target position along the row axis")
 
-    @lazy_property
-    def Nt(self) -> int:
-        return self.N + self.Nc
-
-    @property
-    def F(self) -> int:
-        return self.images.shape[1]
-
-    @property
-    def C(self) -> int:
-        return self.images.shape[2]
+    # -- intensity summaries (per channel) ----------------------------------------------------------------------
+    def _per_channel(self, fn):
+        return torch.stack([fn(self.images[:, :, c]) for c in range(self.C)])
 
     @property
-    def P(self) -> int:
-        Px, Py = self.images.shape[3], self.images.shape[4]
-        assert Px == Py
-        return Px
-
-    @property
-    def x(self) -> torch.Tensor:
-        return self.xy[..., 0]
-
-    @property
-    def y(self) -> torch.Tensor:
-        return self.xy[..., 1]
-
-    @lazy_property
     def median(self) -> torch.Tensor:
-        return torch.stack([torch.median(self.images[..., c, :, :]) for c in range(self.C)])
-
-    def fetch(self, ndx, fdx, cdx):
-        """dataset.py:140-151: gather a minibatch and move it to the compute device."""
-        cpu = lambda i: i.cpu() if isinstance(i, torch.Tensor) and self.images.device.type == "cpu" else i
-        ndx, fdx, cdx = cpu(ndx), cpu(fdx), cpu(cdx)
-        return (
-            self.images[ndx, fdx, cdx].to(self.device),
-            self.xy[ndx, fdx, cdx].to(self.device),
-            self.is_ontarget[ndx].to(self.device),
-        )
+        return self._cached("median", lambda: self._per_channel(torch.median))
 
     def _quantile(self, q):
-        return torch.stack([
-            torch.quantile(self.images[..., c, :, :].flatten().float()[:16_000_000], q) for c in range(self.C)
-        ])
+        # torch.quantile is limited to 16 M elements: the head of the data is representative for display ranges
+        return self._per_channel(lambda im: torch.quantile(im.flatten().float()[:16_000_000], q))
 
-    @lazy_property
+    @property
     def vmin(self) -> torch.Tensor:
-        return self._quantile(0.05)
+        return self._cached("vmin", lambda: self._quantile(0.05))
 
-    @lazy_property
+    @property
     def vmax(self) -> torch.Tensor:
-        return self._quantile(0.99)
+        return self._cached("vmax", lambda: self._quantile(0.99))
+
+    # -- minibatch gather (dataset.py:140-151) -----------------------------------------------------------------
+    def fetch(self, ndx, fdx, cdx):
+        """Images, target positions and on-target flags of a minibatch, on the compute device."""
+        if self.images.device.type == "cpu":
+            ndx, fdx, cdx = (i.cpu() if isinstance(i, torch.Tensor) else i for i in (ndx, fdx, cdx))
+        dev = self.device
+        return self.images[ndx, fdx, cdx].to(dev), self.xy[ndx, fdx, cdx].to(dev), self.is_ontarget[ndx].to(dev)
 
     def __repr__(self):
-        return (f"{self.__class__.__name__}: {self.name}"
-                f"\n  images           tensor(N={self.N} on-target AOIs, Nc={self.Nc} off-target AOIs, "
-                f"F={self.F} frames, C={self.C} channels, P={self.P} pixels, P={self.P} pixels)"
-                f"\n  offset.samples   {self.offset.samples!r}"
-                f"\n        .weights   {self.offset.weights!r}")
+        return (f"{type(self).__name__}: {self.name}\n"
+                f"  images           tensor(N={self.N} on-target AOIs, Nc={self.Nc} off-target AOIs, F={self.F} frames, "
+                f"C={self.C} channels, P={self.P} pixels, P={self.P} pixels)\n"
+                f"  offset.samples   {self.offset.samples!r}\n"
+                f"        .weights   {self.offset.weights!r}")
 
 
 def save(obj, path):
-    """dataset.py:195-212 -- same keys."""
-    path = Path(path)
-    cpu = lambda t: t.cpu() if isinstance(t, torch.Tensor) else t
-    torch.save(
-        {
-            "images": cpu(obj.images), "xy": cpu(obj.xy), "is_ontarget": cpu(obj.is_ontarget),
-            "mask": cpu(obj.mask), "labels": obj.labels,
-            "offset_samples": cpu(obj.offset.samples), "offset_weights": cpu(obj.offset.weights),
-            "name": obj.name, "time1": obj.time1, "ttb": obj.ttb, "channels": obj.channels,
-        },
-        path / "data.tpqr",
-    )
-    logger.info(f"Data is saved in {path / 'data.tpqr'}")
+    """Write ``<path>/data.tpqr`` with the reference's keys (dataset.py:195-212)."""
+    target = Path(path) / DATA_FILE
+    values = {"offset_samples": obj.offset.samples, "offset_weights": obj.offset.weights}
+    payload = {}
+    for key in FILE_KEYS:
+        value = values[key] if key in values else getattr(obj, key)
+        payload[key] = value.cpu() if isinstance(value, torch.Tensor) else value
+    torch.save(payload, target)
+    logger.info(f"Data is saved in {target}")
 
 
 def load(path, device=torch.device("cpu")):
-    """dataset.py:215-222."""
-    path = Path(path)
-    try:
-        data_tapqir = torch.load(path / "data.tpqr", weights_only=False)
-    except FileNotFoundError:
-        raise TapqirFileNotFoundError("data", path / "data.tpqr")
-    return CosmosDataset(**data_tapqir, **{"device": device})
+    """Read ``<path>/data.tpqr`` (dataset.py:215-222); a missing file raises TapqirFileNotFoundError."""
+    source = Path(path) / DATA_FILE
+    if not source.is_file():
+        raise TapqirFileNotFoundError("data", source)
+    return CosmosDataset(**torch.load(source, weights_only=False), device=device)
