@@ -164,7 +164,13 @@ class CosmosEngine:
             a.beta1_d, a.beta2_d = float(self.betas[0]), float(self.betas[1])
             a.crosstalk = int(self.crosstalk)
             a.step = self.adam_step
-            _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), 1, self._stream()), "tq_cosmos_adam_catchup")
+            self._adam_catchup(a, 1)
+
+    def _adam_catchup(self, a, all_units):
+        if self._hostcheck:
+            self.lib.hc_cosmos_adam_catchup(C.byref(a), all_units)
+        else:
+            _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), all_units, self._stream()), "tq_cosmos_adam_catchup")
 
     def reset_adam_clock(self, step=0):
         """The buffers were (re)written from outside (initialisation, checkpoint): everything is current at `step`."""
@@ -322,7 +328,7 @@ class CosmosEngine:
             if not self._stale:
                 self._last_step.fill_(self.adam_step)  # every unit is current: start the clock here
                 self._stale = True
-            _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), 0, self._stream()), "tq_cosmos_adam_catchup")
+            self._adam_catchup(a, 0)
         else:
             self._catch_up_all()
             a.last_step = None  # full batch: no unit falls behind

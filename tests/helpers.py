@@ -49,6 +49,8 @@ def load_hostcheck():
               "hc_cosmos_globals_grad", "hc_cosmos_adam"):
         getattr(lib, n).argtypes = [C.POINTER(_lib.CosmosArgs)]
         getattr(lib, n).restype = None
+    lib.hc_cosmos_adam_catchup.argtypes = [C.POINTER(_lib.CosmosArgs), C.c_int32]
+    lib.hc_cosmos_adam_catchup.restype = None
     lib.hc_cosmos_tail_reduced.argtypes = [C.POINTER(_lib.CosmosArgs), C.POINTER(_lib.CosmosArgs)]
     lib.hc_cosmos_tail_reduced.restype = None
     _hc = lib

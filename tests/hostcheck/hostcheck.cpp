@@ -380,6 +380,15 @@ void hc_cosmos_adam(const tq_cosmos_args* a) {
   const int64_t total = tq_num_params(*a);
   for (int64_t j = a->fuse_adam ? tq_aoi_base(*a) : 0; j < total; ++j) tq_body_adam(*a, j);
 }
+// tq_cosmos_adam_catchup: the loop of tq_adam_catchup_kernel (lazy Adam of minibatch steps)
+void hc_cosmos_adam_catchup(const tq_cosmos_args* a, int32_t all_units) {
+  const int64_t n = all_units ? tq_num_units(*a) : tq_batch_units(*a), U = tq_num_units(*a);
+  for (int r = 0; r < TQ_NLOCAL(a->K); ++r)
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t u = all_units ? i : tq_decode_unit(*a, i).u;
+      tq_adam_replay(*a, (int64_t)r * U + u, a->last_step[u] + 1, (int)a->step);
+    }
+}
 
 }  // extern "C"
 

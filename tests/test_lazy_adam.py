@@ -113,3 +113,33 @@ def test_staged_calls_after_lazy_steps_see_current_parameters():
         out.append(float(eng.elbo_out))
     assert not lazy._stale
     assert abs(out[0] - out[1]) <= 1e-5 * abs(out[0])
+
+
+def test_lazy_adam_on_the_host_build():
+    """The same comparison without a GPU: the kernels' inline code compiled with g++ (tests/hostcheck), lazy against
+    dense Adam over mixed minibatch / full-batch steps, and the replay of never-touched units against the closed loop."""
+    from helpers import load_hostcheck
+
+    d = make_dataset(N=4, F=6, K=2, seed=5)
+    o = make_oracle(d, 2, perturb=0.2, seed=2)
+    engs = []
+    for lazy in (False, True):
+        eng = CosmosEngine(d, K=2, device=torch.device("cpu"), seed=11, lib=load_hostcheck())
+        eng.lazy_adam = lazy
+        oracle_to_engine(o, eng)
+        engs.append(eng)
+    dense, lazy = engs
+    gen = torch.Generator().manual_seed(3)
+    for it in range(14):
+        if it == 8:
+            ndx = fdx = None
+        else:
+            ndx, fdx = torch.randperm(4, generator=gen)[:2], torch.randperm(6, generator=gen)[:3]
+        for eng in engs:
+            eng.step(ndx, fdx)
+        if it in (5, 13):
+            assert lazy._stale
+            for name, tol in (("params", 2e-5), ("exp_avg", 2e-4), ("exp_avg_sq", 2e-4)):
+                assert close(getattr(lazy, name), getattr(dense, name), tol), (it, name)
+            assert not lazy._stale
+    assert dense.adam_step == lazy.adam_step == 14
