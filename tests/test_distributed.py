@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q, async_op=False):
+def _worker(rank, world, port, q, async_op=False, minibatch=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -44,16 +44,27 @@ def _worker(rank, world, port, q, async_op=False):
         else:
             sv[n].copy_(fv[n])
     allreduce = make_allreduce(async_op=async_op)
-    for _ in range(3 if async_op else 2):
-        eng.step(allreduce=allreduce)
+    nsteps = 3 if async_op else 2
+    # minibatch mode: every rank subsamples its own AOIs (local indices) and the common frames; with the lazy Adam
+    # clock the units outside the minibatches are caught up when the parameters are read
+    subs = [([0, 2], [1, 3, 4]), ([1, 2], [0, 2]), ([0, 1], [0, 1, 4]), ([0, 2], [2, 3])] if minibatch else [(None, None)] * nsteps
+    if minibatch:
+        eng.lazy_adam = full.lazy_adam = True
+    t = lambda v: None if v is None else torch.tensor(v)
+    for ndx, fdx in subs:
+        eng.step(t(ndx), t(fdx), allreduce=allreduce)
     if async_op:
         assert eng._pending is not None  # the last step's global tail is still waiting for its collective
+    if minibatch:
+        assert eng._stale
     eng.join()
     out = {"rank": rank, "lo": lo, "hi": hi, "elbo": float(eng.elbo_out[0]),
            "params": {n: v.clone().numpy() for n, v in eng.named("params").items()}}
     if rank == 0:
-        for _ in range(3 if async_op else 2):
-            full.step()
+        per = N // world
+        for ndx, fdx in subs:
+            gn = None if ndx is None else [r * per + j for r in range(world) for j in ndx]  # the union of the ranks' AOIs
+            full.step(t(gn), t(fdx))
         out["full_elbo"] = float(full.elbo_out[0])
         out["full_params"] = {n: v.clone().numpy() for n, v in full.named("params").items()}
     q.put(out)
@@ -62,13 +73,14 @@ def _worker(rank, world, port, q, async_op=False):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("async_op", [False, True], ids=["blocking_allreduce", "overlapped_allreduce"])
-def test_two_rank_sharded_steps_equal_single_process(async_op):
+@pytest.mark.parametrize("async_op,minibatch", [(False, False), (True, False), (True, True)],
+                         ids=["blocking_allreduce", "overlapped_allreduce", "minibatch_lazy_adam"])
+def test_two_rank_sharded_steps_equal_single_process(async_op, minibatch):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 7 * int(async_op)) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, async_op)) for r in range(world)]
+    port = 29500 + (os.getpid() + 7 * int(async_op) + 13 * int(minibatch)) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, async_op, minibatch)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o["rank"])
