@@ -323,3 +323,33 @@ def test_read_glimpse_more_aois_than_one_launch_covers(tmp_path):
     assert ds.images.shape == (70000, 2, 1, 6, 6)
     assert torch.equal(ds.images, want["images"]) and torch.equal(ds.xy, want["xy"])
     assert torch.equal(ds.offset.samples.cpu(), want["offset_samples"]) and torch.equal(ds.offset.weights.cpu(), want["offset_weights"])
+
+
+def golden_case():
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_glimpse_golden.py")
+    spec = importlib.util.spec_from_file_location("make_glimpse_golden", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, np.load(os.path.join(os.path.dirname(path), "glimpse_golden.npz"))
+
+
+def test_oracle_reproduces_the_committed_golden_output():
+    mod, gold = golden_case()
+    now = mod.build()
+    for key in gold.files:
+        assert np.array_equal(now[key], gold[key]), key
+
+
+@pytest.mark.gpu
+def test_read_glimpse_matches_the_committed_golden_output(tmp_path):
+    mod, gold = golden_case()
+    cfg, _ = write_experiment(tmp_path / "raw", **mod.CASE)
+    cfg["bin-size"] = 3
+    ds = read_glimpse(tmp_path, None, **cfg)
+    assert np.array_equal(ds.images.numpy(), gold["images"]) and np.array_equal(ds.xy.numpy(), gold["xy"])
+    assert np.array_equal(ds.offset.samples.cpu().numpy(), gold["offset_samples"])
+    assert np.array_equal(ds.offset.weights.cpu().numpy(), gold["offset_weights"])
+    assert np.array_equal(ds.labels["z"], gold["labels_z"]) and np.array_equal(ds.ttb.numpy(), gold["ttb"])
