@@ -859,7 +859,7 @@ __device__ __forceinline__ void tq_pair_multi_offset(TqPixAcc<K>& A, const tq_ks
       cv[mi] = -av[mi] * tq2_log2(vs[mi] * rvhi);
       S0[mi] = S1[mi] = S2[mi] = tq2(0.0f);
     }
-#pragma unroll 2
+#pragma unroll 4
     for (int o = 0; o < a.O; ++o) {
       const float so = a.offset_samples[o];
       const float2 tb = s_tab[o];
