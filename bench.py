@@ -1,29 +1,34 @@
 """
 Benchmark of the cosmos SVI hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py                                  # 1 GPU, BASELINE config c2, K steps x 5 blocks
+    python bench.py --gpus N --steps K --warmup W    # starts its own N rank processes (one per GPU, RCCL)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same ranks, outer launcher)
 
-Workload (BASELINE.json configs[1]): cosmos K=2, 400 AOIs x 1000 frames, P=14, synthetic data with
-the law of tapqir/utils/simulate.py and the reference test-suite parameters; one *step* = one
-complete SVI update (guide draws -> ELBO -> gradients -> dense Adam) over the full batch held
-by the rank.  With N ranks every rank holds its own 400 x 1000 shard (AOI-sharded, weak
-scaling) and the only communication is one all-reduce of the 6 cross-unit sums per step.
+Workload (BASELINE.json configs[1] = "c2"): cosmos K=2, 400 AOIs x 1000 frames, P=14, synthetic data with the law of
+tapqir/utils/simulate.py and the reference test-suite parameters; one *step* = one complete SVI update (guide draws ->
+ELBO -> gradients -> dense Adam) over the full batch held by the rank.  With N ranks every rank holds its own shard
+(AOI-sharded, weak scaling: `--config c2` = 400 x 1000 per GPU) and the only communication is ONE all-reduce of the
+cross-unit sums per step.  `--config c3` / `c5` / `c4` put the per-GPU shard of the other BASELINE configs on every rank
+(c3: 400 x 4000, = BASELINE c3 itself at N = 8; c5: K=3 P=20 250 x 2000, = c5 itself at N = 4; c4: crosstalk
+400 x 1000 x 2 channels); with `--config auto` (default) the headline is c2 per GPU and a run at N = 8 / N = 4 appends the
+c3 / c5 figures as `north_star_configs`.
 
-Prints ONE JSON line (rank 0).  `value` = AOI-frames/s over all ranks; also reported:
-ELBO steps/s, the reference's default-minibatch operating point, the HBM roofline of the fused
-spot-render + log-prob kernel (HIP-event timing on its own stream) and the CPU baseline
-(oracle = dense-torch float64 restatement, timed on this box's host cores).
+Prints ONE JSON line (rank 0).  `value` = AOI-frames/s over all ranks (median of `--blocks` timed blocks of exactly
+`--steps` steps, each bracketed by barrier + synchronize, max over ranks); also reported: ELBO steps/s, the reference's
+default-minibatch operating point, the trained-parameter regime, the HBM roofline of the fused spot-render + log-prob
+kernel (HIP-event timing on its own stream) and the CPU baseline (oracle = dense-torch restatement, timed on this box's
+host cores, float64 as `tapqir fit` and float32 for information).
 """
 
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -32,10 +37,23 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X nominal HBM3E bandwidth (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
+# per-GPU shards of the BASELINE.json configs: (model, K, P, AOIs per GPU, frames, channels, ranks at which it IS the config)
+CONFIGS = {
+    "c2": ("cosmos", 2, 14, 400, 1000, 1, 1),
+    "c3": ("cosmos", 2, 14, 400, 4000, 1, 8),
+    "c4": ("crosstalk", 2, 14, 400, 1000, 2, 1),
+    "c5": ("cosmos", 3, 20, 250, 2000, 1, 4),
+}
+
 
 def fwd_bytes_per_unit(K, P):
     """SURVEY.md 8(d): tile + xy + (h,w,x,y per spot; b) + 2^K outputs, fp32."""
     return 4 * P * P + 8 + 4 * (4 * K + 1) + 4 * 2**K
+
+
+def bwd_bytes_per_unit(K, P):
+    """The kernel a step runs also reads the K m_probs logits and writes the 2+4K pathwise gradients (VERDICT r1 #3)."""
+    return fwd_bytes_per_unit(K, P) + 4 * K + 4 * (2 + 4 * K)
 
 
 def step_bytes_per_unit(K, P):
@@ -45,22 +63,157 @@ def step_bytes_per_unit(K, P):
 
 def pmc_traffic(K, P, units, backward):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 correction applied; profiles/r01_pmc_traffic.json says how).  PMC collection cannot run
+    separate runs, gfx950 correction applied; profiles/*_pmc_traffic.json says how).  PMC collection cannot run
     inside this process, so the figure is the measured one for this exact kernel and shape, else None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-    except OSError:
-        return None
-    if (d.get("K"), d.get("P"), d.get("units")) != (K, P, units):
-        return None
-    k = d["kernels"].get(f"tq_ksmogn_il2_kernel<{K}, {P}, {'true' if backward else 'false'}>")
-    return None if k is None else k["traffic_bytes"]
+    prof = os.path.join(ROOT, "profiles")
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(prof, name)))
+        except OSError:
+            continue
+        if (d.get("K"), d.get("P"), d.get("units")) != (K, P, units):
+            continue
+        for kname, k in d["kernels"].items():
+            if kname.endswith(f"<{K}, {P}, {'true' if backward else 'false'}>"):
+                return k["traffic_bytes"], name
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parent: start one process per GPU.  Nothing in this function (or before it in main) touches the GPU.
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    import torch
+
+    n = args.gpus
+    have = torch.cuda.device_count()  # does not initialise the HIP runtime
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the process this launcher started
+        rc = rc or p.returncode
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Problem:
+    """Synthetic data + engine of one rank for one config."""
+
+    def __init__(self, cfg, rank, world, dev, offsets="sim", aois=None, frames=None):
+        import torch
+
+        from tapqir_amd.models.cosmos import initial_values
+        from tapqir_amd.models.crosstalk import crosstalk_initial_values
+        from tapqir_amd.models.engine import CosmosEngine
+        from tapqir_amd.utils.dataset import CosmosDataset
+        from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+        model, K, P, N, F, Cc, at = CONFIGS[cfg]
+        N, F = aois or N, frames or F
+        self.cfg, self.model, self.K, self.P, self.N, self.F, self.C, self.is_config_at = cfg, model, K, P, N, F, Cc, at
+        self.world, self.rank = world, rank
+        xt = model == "crosstalk"
+
+        class _M:  # minimal "model" for simulate(): K and device
+            pass
+
+        _M.K, _M.device = K, dev
+        sim_params = dict(TEST_PARAMS, alpha=[[0.9, 0.1], [0.2, 0.8]]) if xt else TEST_PARAMS
+        data = simulate(_M, N, F, Cc, P, seed=1000 + rank, params=sim_params)
+        if offsets == "hist":
+            s = torch.arange(70.0, 120.0)
+            w = torch.minimum(s - 69.0, 120.0 - s)
+            data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s, offset_weights=w / w.sum())
+        self.data = data
+        self.eng = CosmosEngine(data, K=K, device=dev, seed=7, n_offset=rank * N, Nt_global=world * N, crosstalk=xt)
+        # initial parameter values of the reference (cosmos.py:471-598, crosstalk.py:424-455)
+        self.eng.layout.set_constrained(self.eng.params, (crosstalk_initial_values if xt else initial_values)(self.eng, data))
+        self.offsets = offsets
+
+    def workload(self):
+        at = self.is_config_at
+        same = " (= BASELINE config %s itself)" % self.cfg if self.world == at else \
+            f" (per-GPU shard of BASELINE config {self.cfg}, which spans {at} GPUs)" if at > 1 else ""
+        return (f"{self.model} K={self.K}, {self.N} AOIs x {self.F} frames x {self.C} channel(s) per GPU, P={self.P}, "
+                f"full-batch SVI step (sample guide, ELBO, gradients, dense Adam); offsets={self.offsets} "
+                f"(O={self.eng.O} after merging){same}")
+
+
+class Runner:
+    def __init__(self, use_dist, dev):
+        self.use_dist, self.dev = use_dist, dev
+        self.allreduce = None
+        if use_dist:
+            import torch.distributed as dist
+
+            # left in flight: the engine overlaps it with the next step's local guide sampling (full-batch steps)
+            self.allreduce = lambda t: dist.all_reduce(t, async_op=True)
+
+    def run(self, eng, n, ndx=None, fdx=None):
+        for _ in range(n):
+            eng.step(ndx, fdx, allreduce=self.allreduce)
+        eng.join()  # the last step's deferred global tail belongs to the timed region
+
+    def barrier(self):
+        import torch
+
+        if self.use_dist:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_blocks(self, eng, steps, warmup, blocks):
+        """`blocks` timed regions of exactly `steps` steps, each bracketed by barrier + synchronize; per block the MAX
+        over ranks.  Returns (median block seconds, all block seconds, this run's per-rank seconds of the median block)."""
+        import torch
+
+        self.run(eng, warmup)
+        per_block, per_rank = [], []
+        for _ in range(blocks):
+            self.barrier()
+            t0 = time.perf_counter()
+            self.run(eng, steps)
+            self.barrier()
+            dt = time.perf_counter() - t0
+            ranks = [dt]
+            if self.use_dist:
+                import torch.distributed as dist
+
+                tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+                allt = [torch.zeros_like(tt) for _ in range(dist.get_world_size())]
+                dist.all_gather(allt, tt)
+                ranks = [float(t) for t in allt]
+            per_block.append(max(ranks))
+            per_rank.append(ranks)
+        order = sorted(range(blocks), key=lambda i: per_block[i])
+        mid = order[(blocks - 1) // 2]
+        return per_block[mid], per_block, per_rank[mid]
 
 
 def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
     """Device-to-device copy rate (read + write bytes per second, GB/s): what this box's HBM delivers to a plain
     streaming kernel; quoted next to the nominal 8 TB/s peak."""
+    import torch
+
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
     b.copy_(a)
@@ -75,7 +228,9 @@ def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
 
 
 def time_pixel_kernel(eng, launches, backward):
-    """Average duration of the fused render+log-prob kernel, HIP events on its launch stream."""
+    """Average duration of the fused render+log-prob kernel (cosmos or crosstalk), HIP events on its launch stream."""
+    import torch
+
     from tapqir_amd import _lib
 
     a = eng.make_args()
@@ -84,11 +239,12 @@ def time_pixel_kernel(eng, launches, backward):
     eng.call("cosmos_sample_locals", a)
     K, M = eng.K, 1 << eng.K
     B = eng.Nt * eng.F * eng.C
-    k = _lib.KsmognArgs()
+    xt = eng.crosstalk
+    k = _lib.XtalkArgs() if xt else _lib.KsmognArgs()
     p = _lib.ptr
     k.images, k.images_il, k.xy, k.ndx, k.fdx = p(eng.images), p(eng.images_il), p(eng.xy), None, None
     k.nb_full, k.il_min_units = eng.Nt, eng.il_min_units
-    k.pixstats, k.stats_stride = p(eng.pixstats), B
+    k.pixstats = p(eng.pixstats)
     lat = eng.lat
     f = lambda row: lat.data_ptr() + 4 * row * B
     k.background, k.height, k.width, k.x, k.y = f(0), f(1), f(1 + K), f(1 + 2 * K), f(1 + 3 * K)
@@ -98,84 +254,154 @@ def time_pixel_kernel(eng, launches, backward):
     pix = eng.pix
     g = lambda row: pix.data_ptr() + 4 * row * B
     k.ll = g(0)
+    if xt:
+        k.alpha = eng.globals.data_ptr() + 4 * 21  # TqGlobals.alpha (tq_site.h)
+        k.ll_joint = None
+        k.ell_excess = g(M + 2 + 4 * K)
+        k.g_alpha = g(M + 3 + 4 * K)
+    else:
+        k.stats_stride = B
     if backward:
         k.g_background, k.g_gain = g(M), g(M + 1)
         k.g_height, k.g_width, k.g_x, k.g_y = g(M + 2), g(M + 2 + K), g(M + 2 + 2 * K), g(M + 2 + 3 * K)
     k.m_kstride = B
     k.nb, k.fb, k.C, k.F, k.P, k.K, k.O = eng.Nt, eng.F, eng.C, eng.F, eng.P, K, eng.O
     k.scale = 1.0
+    fn = eng.lib.tq_ksmogn_crosstalk_log_prob if xt else eng.lib.tq_ksmogn_log_prob
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     for _ in range(3):
-        _lib.check(eng.lib.tq_ksmogn_log_prob(C.byref(k), sp), "tq_ksmogn_log_prob")
+        _lib.check(fn(C.byref(k), sp), "pixel kernel")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(launches):
-        eng.lib.tq_ksmogn_log_prob(C.byref(k), sp)
+        fn(C.byref(k), sp)
     e1.record(stream)
     e1.synchronize()
     return e0.elapsed_time(e1) / launches * 1e-3  # seconds
 
 
-def cpu_baseline(data, K, nb, fb, steps=5, warmup=2):
-    """Oracle (dense torch float64 = the tensor program Pyro would run) on the host cores."""
-    from oracle.cosmos import CosmosOracle, OracleData
+def cpu_baseline(data, K, nb, fb, steps=5, warmup=2, dtype="float64", threads=None):
+    """Oracle (dense torch = the tensor program Pyro would run) on the host cores."""
+    import torch
 
-    od = OracleData(data.images[:nb, :fb].cpu(), data.xy[:nb, :fb].cpu(), data.is_ontarget[:nb].cpu(),
-                    data.offset.samples.cpu(), data.offset.weights.cpu())
-    o = CosmosOracle(od, K=K)
-    o.init_parameters()
-    o.make_optim(lr=0.005)
-    nd, fd = torch.arange(nb), torch.arange(fb)
-    # torch's intra-op pool does not scale to hundreds of host threads on these tensor sizes:
-    # take the thread count that runs this step fastest (one probe step each) and say which it was
-    best = None
-    for nt in sorted({t for t in (8, 16, 32, 64, os.cpu_count()) if t <= os.cpu_count()}):
-        torch.set_num_threads(nt)
-        o.step(nd, fd)
-        t0 = time.perf_counter()
-        o.step(nd, fd)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, nt)
-    torch.set_num_threads(best[1])
-    ts = []
-    for it in range(warmup + steps):
-        t0 = time.perf_counter()
-        o.step(nd, fd)
-        if it >= warmup:
-            ts.append(time.perf_counter() - t0)
+    from oracle import cosmos as oc
+
+    with oc.working_dtype(getattr(torch, dtype)):
+        od = oc.OracleData(data.images[:nb, :fb].cpu(), data.xy[:nb, :fb].cpu(), data.is_ontarget[:nb].cpu(),
+                           data.offset.samples.cpu(), data.offset.weights.cpu())
+        o = oc.CosmosOracle(od, K=K, eps=float(torch.finfo(torch.float32).eps) if dtype == "float32" else None)
+        o.init_parameters()
+        o.make_optim(lr=0.005)
+        nd, fd = torch.arange(nb), torch.arange(fb)
+        # torch's intra-op pool does not scale to hundreds of host threads on these tensor sizes:
+        # take the thread count that runs this step fastest (one probe step each) and say which it was
+        if threads is None:
+            best = None
+            for nt in sorted({t for t in (8, 16, 32, 64, os.cpu_count()) if t <= os.cpu_count()}):
+                torch.set_num_threads(nt)
+                o.step(nd, fd)
+                t0 = time.perf_counter()
+                o.step(nd, fd)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, nt)
+            threads = best[1]
+        torch.set_num_threads(threads)
+        ts = []
+        for it in range(warmup + steps):
+            t0 = time.perf_counter()
+            loss = o.step(nd, fd)
+            if it >= warmup:
+                ts.append(time.perf_counter() - t0)
+        assert loss == loss, "CPU baseline produced a NaN loss"
     ts.sort()
     med = ts[len(ts) // 2]
     return {"value": nb * fb / med, "unit": "AOI-frames/s", "cores": torch.get_num_threads(),
-            "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"oracle dense-torch float64 full SVI step, nb={nb} x fb={fb} units of the same data, "
+            "host_cpus": os.cpu_count(), "kind": "port", "dtype": dtype,
+            "sample": f"oracle dense-torch {dtype} full SVI step, nb={nb} x fb={fb} units of the same data, "
                       f"median of {steps} steps after {warmup} warm-up ({med:.2f} s/step = {1 / med:.3f} steps/s)",
             "steps_per_sec_at_sample": 1 / med}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--aois", type=int, default=400)
-    ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--K", type=int, default=2)
-    ap.add_argument("--P", type=int, default=14)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--offsets", default="sim", choices=["sim", "hist"])
-    ap.add_argument("--model", default="cosmos", choices=["cosmos", "crosstalk"],
-                    help="crosstalk = BASELINE config c4 (Q = C = 2, alpha = [[.9,.1],[.2,.8]]); not the headline metric")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="rehearsal: take the multi-GPU code path (process group, staged step, all-reduce) with one rank")
-    args = ap.parse_args()
+def roofline_block(pb, ms_per_step, dev):
+    import torch
+
+    eng, K, P = pb.eng, pb.K, pb.P
+    units = pb.N * pb.F * (1 if eng.crosstalk else pb.C)  # crosstalk: one (C, P, P) tile per AOI-frame
+    t_fb = time_pixel_kernel(eng, 20, backward=True)
+    t_f = time_pixel_kernel(eng, 20, backward=False)
+    if eng.crosstalk:
+        # one launch covers all C channels of an AOI-frame: C tiles + C (xy, b) + Q dyes x K spots + the 2^K marginals per dye
+        bpu = pb.C * (4 * P * P + 8 + 4) + pb.C * (16 * K + 4 * 2**K)
+        kernel = "tq_xtalk_il_kernel<K,P,bwd> (coupled-dye render + log-prob of the 2^(KQ) joint combinations + pathwise grads)"
+    else:
+        bpu = fwd_bytes_per_unit(K, P)
+        kernel = "tq_ksmogn_il2_kernel<K,P,bwd> (fused render + log-prob + pathwise grads; packed lane-per-unit)" \
+            if eng.O == 1 else "tq_ksmogn_il2m_kernel<K,bwd> (offset-histogram form of the same kernel)"
+    ach = units * bpu / t_fb / 1e9
+    traffic, tsrc = (pmc_traffic(K, P, units, True) if (pb.offsets == "sim" and not eng.crosstalk) else (None, None))
+    sb = step_bytes_per_unit(K, P)
+    tot_units = pb.N * pb.F * pb.C
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": traffic,
+           "traffic_unit": f"bytes/launch (PMC, profiles/{tsrc}); algorithmic = bytes_per_unit x units_per_launch",
+           "kernel": kernel, "bytes_per_unit": bpu, "units_per_launch": units, "avg_launch_ms": t_fb * 1e3,
+           "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": units * bpu / t_f / 1e9,
+                            "frac": units * bpu / t_f / 1e9 / HBM_PEAK_GBS},
+           "whole_step": {"bytes_per_unit": sb, "achieved": tot_units * sb / (ms_per_step * 1e-3) / 1e9,
+                          "frac": tot_units * sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if not eng.crosstalk:
+        bb = bwd_bytes_per_unit(K, P)
+        out["with_gradient_outputs"] = {"bytes_per_unit": bb, "achieved": units * bb / t_fb / 1e9,
+                                        "frac": units * bb / t_fb / 1e9 / HBM_PEAK_GBS,
+                                        "note": "bytes_per_unit + K m_probs logits read + (2+4K) gradient rows written"}
+    if eng.O > 1:
+        # the offset-histogram kernel is bound by the transcendental pipe, not by HBM: (K+1) + 1 exp2/log2 per
+        # (offset, pixel); peak = v_exp_f32 issue rate of profiles/r01_valu_issue_rates.txt (8 cycles per wave64) x 1024 SIMDs
+        per_unit = P * P * eng.O * (K + 2)
+        peak = 1024 * 64 / 8 * 2.4e9 / 1e12
+        out["transcendental"] = {"bound": "transcendental", "per_unit": per_unit,
+                                 "achieved": units * per_unit / t_fb / 1e12, "peak": peak, "unit": "Ttrans/s",
+                                 "frac": units * per_unit / t_fb / 1e12 / peak}
+    bw = measured_copy_bandwidth(dev)
+    out["peak_measured_copy"] = bw
+    out["frac_of_measured_copy"] = ach / bw
+    out["forward_only"]["frac_of_measured_copy"] = out["forward_only"]["achieved"] / bw
+    return out
+
+
+def headline(pb, runner, args, prewarm=True):
+    """Timed full-batch steps of one problem -> dict of the headline fields."""
+    eng = pb.eng
+    if prewarm:
+        # The first ~1000 kernel launches of a process end with ONE host-side stall of ~80 ms inside the HIP runtime
+        # (scripts/diag_hiccup.py; the GPU is idle meanwhile).  Push the process past that point first.
+        runner.run(eng, 400)
+        runner.barrier()
+    med, blocks, per_rank = runner.timed_blocks(eng, args.steps, args.warmup, args.blocks)
+    ms = med / args.steps * 1e3
+    units = pb.world * pb.N * pb.F
+    import torch
+
+    eng.join()
+    assert torch.isfinite(eng.params).all(), "non-finite parameters after the timed steps"
+    return {"value": units / (med / args.steps), "ms_per_step": ms, "elbo_steps_per_sec": 1e3 / ms,
+            "block_ms_per_step": [b / args.steps * 1e3 for b in blocks],
+            "per_rank_ms_per_step": [r / args.steps * 1e3 for r in per_rank],
+            "final_elbo": float(eng.elbo_out[0]), "workload": pb.workload()}
+
+
+def worker(args):
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     use_dist = world > 1 or args.force_dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if use_dist:
         import torch.distributed as dist
 
@@ -183,141 +409,128 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()  # what the process group says, not the environment
+        rank = dist.get_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
 
-    from tapqir_amd.models.engine import CosmosEngine
-    from tapqir_amd.utils.dataset import CosmosDataset
-    from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
-
-    class _M:  # minimal "model" for simulate(): K and device
-        K, device = args.K, dev
-
-    N, F, K, P = args.aois, args.frames, args.K, args.P
-    xt = args.model == "crosstalk"
-    Cc = 2 if xt else 1
-    sim_params = dict(TEST_PARAMS, alpha=[[0.9, 0.1], [0.2, 0.8]]) if xt else TEST_PARAMS
-    data = simulate(_M, N, F, Cc, P, seed=1000 + rank, params=sim_params)
-    if args.offsets == "hist":
-        s = torch.arange(70.0, 120.0)
-        w = torch.minimum(s - 69.0, 120.0 - s)
-        data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s, offset_weights=w / w.sum())
-    eng = CosmosEngine(data, K=K, device=dev, seed=7, n_offset=rank * N, Nt_global=world * N, crosstalk=xt)
-    # initial parameter values of the reference (cosmos.py:471-598, crosstalk.py:424-455)
-    from tapqir_amd.models.cosmos import initial_values
-    from tapqir_amd.models.crosstalk import crosstalk_initial_values
-
-    eng.layout.set_constrained(eng.params, (crosstalk_initial_values if xt else initial_values)(eng, data))
-
-    allreduce = None
-    if use_dist:
-        def allreduce(t):
-            # left in flight: the engine overlaps it with the next step's local guide sampling (full-batch steps)
-            return dist.all_reduce(t, async_op=True)
-
-    def run(n, ndx=None, fdx=None):
-        for _ in range(n):
-            eng.step(ndx, fdx, allreduce=allreduce)
-        eng.join()  # the last step's deferred global tail belongs to the timed region
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- process initialisation: grow the HIP runtime's launch resources ---------------------------------
-    # The first ~1000 kernel launches of a process end with ONE host-side stall of ~80 ms inside the
-    # HIP runtime (measured: scripts/diag_hiccup.py; the GPU is idle meanwhile, no kernel of ours is
-    # involved).  Push the process past that point before the warm-up/timed steps the driver asks for.
-    run(400)  # >= 1500 launches with 4 launches per pipelined step
-    barrier()
-
-    # ---- headline: full-batch steps -----------------------------------------------------------------
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
-    ms_per_step = dt / args.steps * 1e3
-    units_per_step = world * N * F
-    value = units_per_step / (dt / args.steps)
-    eng.join()
-    elbo = float(eng.elbo_out[0])
-    assert torch.isfinite(eng.params).all(), "non-finite parameters after the timed steps"
+    runner = Runner(use_dist, dev)
+    cfg = "c2" if args.config == "auto" else args.config
+    pb = Problem(cfg, rank, world, dev, offsets=args.offsets, aois=args.aois, frames=args.frames)
+    eng = pb.eng
+    h = headline(pb, runner, args)
     # host side of a step (outside the timed region): time to ENQUEUE 20 steps on an idle queue; if it approaches
     # ms_per_step the launch path, not the GPU, sets the pace
-    barrier()
+    runner.barrier()
     th = time.perf_counter()
     for _ in range(20):
-        eng.step(allreduce=allreduce)
+        eng.step(allreduce=runner.allreduce)
     host_ms = (time.perf_counter() - th) / 20 * 1e3
     eng.join()
-    barrier()
+    runner.barrier()
 
     out = {
-        "metric": f"{args.model} SVI AOI-frames/s (= ELBO steps/s x nb x fb), K=2 P=14 full batch",
-        "value": value, "unit": "AOI-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": host_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.model} K={K}, {N} AOIs x {F} frames x {Cc} channel(s) per GPU, P={P}, full-batch SVI step "
-                               f"(sample guide, ELBO, gradients, dense Adam); offsets={args.offsets} (O={eng.O} after merging)",
-                   "nb": N, "fb": F, "aoi_sharding": f"{world} x {N} AOIs"},
-        "elbo_steps_per_sec": 1e3 / ms_per_step,
-        "final_elbo": elbo,
+        "metric": f"{pb.model} SVI AOI-frames/s (= ELBO steps/s x nb x fb), K={pb.K} P={pb.P} full batch",
+        "value": h["value"], "unit": "AOI-frames/s", "n_gpus": world,
+        "rccl_ranks": (dist.get_world_size() if use_dist else 1), "backend": (dist.get_backend() if use_dist else "none"),
+        "steps": args.steps, "warmup": args.warmup, "blocks": args.blocks,
+        "ms_per_step": h["ms_per_step"], "block_ms_per_step": h["block_ms_per_step"],
+        "per_rank_ms_per_step": h["per_rank_ms_per_step"], "host_enqueue_ms_per_step": host_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": h["workload"], "baseline_config": cfg, "nb": pb.N, "fb": pb.F,
+                   "aoi_sharding": f"{world} x {pb.N} AOIs"},
+        "elbo_steps_per_sec": h["elbo_steps_per_sec"], "final_elbo": h["final_elbo"],
     }
 
-    if rank == 0:
+    if world == 1 and not args.quick:
         # ---- reference default minibatch operating point (main.py:1429-1430): nb=10, fb=512 ----------
-        if world == 1:
-            nb, fb = min(10, N), min(512, F)
-            g = torch.Generator(device="cpu").manual_seed(0)
-            idx = [(torch.randperm(N, generator=g)[:nb], torch.randperm(F, generator=g)[:fb]) for _ in range(20)]
-            for nd, fd in idx[:3]:
-                eng.step(nd, fd)
+        nb, fb = min(10, pb.N), min(512, pb.F)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        idx = [(torch.randperm(pb.N, generator=g)[:nb], torch.randperm(pb.F, generator=g)[:fb]) for _ in range(100)]
+        for nd, fd in idx[:10]:
+            eng.step(nd, fd)
+        mbs = []
+        for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for nd, fd in idx:
                 eng.step(nd, fd)
+            eng.join()
             torch.cuda.synchronize()
-            mb = (time.perf_counter() - t0) / len(idx)
-            out["minibatch_10x512"] = {"ms_per_step": mb * 1e3, "steps_per_sec": 1 / mb,
-                                       "aoi_frames_per_sec": nb * fb / mb}
-        if not xt:  # (the crosstalk likelihood kernel is not the headline's dominant kernel: step figures only)
-            # ---- roofline of the dominant kernel -----------------------------------------------------------
-            t_fb = time_pixel_kernel(eng, 20, backward=True)
-            t_f = time_pixel_kernel(eng, 20, backward=False)
-            bpu = fwd_bytes_per_unit(K, P)
-            ach = N * F * bpu / t_fb / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(K, P, N * F, True) if args.offsets == "sim" else None,
-                               "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json); algorithmic = bytes_per_unit x units_per_launch",
-                               "kernel": "tq_ksmogn_il2_kernel<K,P,bwd> (fused render + log-prob + pathwise grads; packed lane-per-unit)",
-                               "bytes_per_unit": bpu, "units_per_launch": N * F, "avg_launch_ms": t_fb * 1e3,
-                               "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": N * F * bpu / t_f / 1e9,
-                                                "frac": N * F * bpu / t_f / 1e9 / HBM_PEAK_GBS},
-                               "whole_step": {"bytes_per_unit": step_bytes_per_unit(K, P),
-                                              "achieved": N * F * step_bytes_per_unit(K, P) / (ms_per_step * 1e-3) / 1e9,
-                                              "frac": N * F * step_bytes_per_unit(K, P) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-            bw = measured_copy_bandwidth(dev)
-            out["roofline"]["peak_measured_copy"] = bw
-            out["roofline"]["frac_of_measured_copy"] = ach / bw
-            out["roofline"]["forward_only"]["frac_of_measured_copy"] = out["roofline"]["forward_only"]["achieved"] / bw
-            if not args.no_cpu:
-                out["cpu_baseline"] = cpu_baseline(data, K, min(10, N), min(512, F))
+            mbs.append((time.perf_counter() - t0) / len(idx))
+        mb = sorted(mbs)[2]
+        out["minibatch_10x512"] = {"ms_per_step": mb * 1e3, "steps_per_sec": 1 / mb, "aoi_frames_per_sec": nb * fb / mb,
+                                   "protocol": "median of 5 blocks of 100 steps, fresh random subsample every step"}
+        # ---- roofline of the dominant kernel -----------------------------------------------------------
+        out["roofline"] = roofline_block(pb, h["ms_per_step"], dev)
+        # ---- trained-parameter regime: guide concentrations shrink as the fit converges and other regimes of the
+        # implicit reparameterisation gradients take over ------------------------------------
+        if args.trained_steps > 0 and cfg == "c2" and args.offsets == "sim":
+            runner.run(eng, args.trained_steps)
+            med, blocks, _ = runner.timed_blocks(eng, args.steps, 0, args.blocks)
+            out["trained_regime"] = {"after_steps": args.trained_steps, "ms_per_step": med / args.steps * 1e3,
+                                     "value": pb.N * pb.F / (med / args.steps), "final_elbo": float(eng.elbo_out[0])}
+        if not args.no_cpu and pb.model == "cosmos":
+            out["cpu_baseline"] = cpu_baseline(pb.data, pb.K, min(10, pb.N), min(512, pb.F))
+            f32 = cpu_baseline(pb.data, pb.K, min(10, pb.N), min(512, pb.F), dtype="float32",
+                               threads=out["cpu_baseline"]["cores"])
+            out["cpu_baseline"]["float32"] = {k: f32[k] for k in ("value", "steps_per_sec_at_sample", "sample", "cores")}
+
+    # ---- the other BASELINE configs at the rank counts they are quoted on (driver's SCALE run: N = 8 -> c3, N = 4 -> c5)
+    extra = []
+    if args.config == "auto" and args.offsets == "sim" and not args.quick:
+        extra = {8: ["c3"], 4: ["c5"]}.get(world, [])
+    if args.also:
+        extra += [c for c in args.also.split(",") if c and c != cfg]
+    if extra:
+        out["north_star_configs"] = {}
+        del pb, eng
+        torch.cuda.empty_cache()
+        for c in extra:
+            pe = Problem(c, rank, world, dev)
+            he = headline(pe, runner, args, prewarm=False)
+            entry = {k: he[k] for k in ("value", "ms_per_step", "block_ms_per_step", "per_rank_ms_per_step", "workload")}
+            entry.update(unit="AOI-frames/s", n_gpus=world, is_the_config=(world == pe.is_config_at))
+            if world == 1:
+                entry["roofline"] = roofline_block(pe, he["ms_per_step"], dev)
+            out["north_star_configs"][c] = entry
+            del pe
+            torch.cuda.empty_cache()
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--config", default="auto", choices=["auto"] + sorted(CONFIGS),
+                    help="BASELINE.json config whose per-GPU shard every rank holds (auto = c2, plus c3 at 8 ranks / c5 at 4)")
+    ap.add_argument("--also", default="", help="comma-separated configs to time after the headline (north_star_configs)")
+    ap.add_argument("--aois", type=int, default=None, help="override the AOIs per GPU of the config")
+    ap.add_argument("--frames", type=int, default=None, help="override the frames of the config")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--quick", action="store_true", help="headline only (no minibatch / roofline / CPU legs)")
+    ap.add_argument("--trained-steps", type=int, default=4000, help="steps before the trained-regime leg (0 = skip)")
+    ap.add_argument("--offsets", default="sim", choices=["sim", "hist"])
+    ap.add_argument("--model", default=None, choices=["cosmos", "crosstalk"], help="crosstalk = --config c4")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the multi-GPU code path (process group, staged step, all-reduce) with one rank")
+    args = ap.parse_args()
+    if args.model == "crosstalk":
+        args.config = "c4"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])  # parent: never touches the GPU
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -22,6 +22,7 @@ Gaussian stack and the (..., P, P, O) mixture and uses autograd -- the same tens
 Pyro would execute -- so it also serves as the CPU baseline of bench.py.
 """
 
+import contextlib
 import itertools
 import math
 
@@ -33,9 +34,23 @@ from torch.distributions.utils import probs_to_logits
 from .dist_util import expand_offtarget, probs_m, probs_theta
 from .ksmogn import ksmogn_log_prob
 
+# Working dtype of the restatement.  float64 is what `tapqir fit` runs (main.py:428) and what every parity test uses;
+# bench.py's cpu_baseline leg also times a float32 pass "for information" (BASELINE.md section 3).
+_DT = [torch.float64]
+
+
+@contextlib.contextmanager
+def working_dtype(dtype):
+    old, _DT[0] = _DT[0], dtype
+    try:
+        yield
+    finally:
+        _DT[0] = old
+
+
 def _t(v):
     """python scalars -> float64 tensors (the reference runs with float64 as default dtype, main.py:428)."""
-    return torch.as_tensor(v, dtype=torch.float64)
+    return torch.as_tensor(v, dtype=_DT[0])
 
 
 DEFAULT_PRIORS = {  # tapqir/models/cosmos.py:55-64
@@ -129,7 +144,7 @@ class OracleData:
     """The slice of tapqir/utils/dataset.py (CosmosDataset/OffsetData) the step needs."""
 
     def __init__(self, images, xy, is_ontarget, offset_samples, offset_weights, mask=None):
-        dt = torch.float64
+        dt = _DT[0]
         self.images = images.to(dt)  # (Nt, F, C, P, P)
         self.xy = xy.to(dt)  # (Nt, F, C, 2)
         self.is_ontarget = is_ontarget.bool()
@@ -185,10 +200,10 @@ class CosmosOracle:
 
     def init_values(self):
         d, K, Q = self.data, self.K, self.Q
-        f = lambda shape, v: torch.full(shape, float(v), dtype=torch.float64)
+        f = lambda shape, v: torch.full(shape, float(v), dtype=_DT[0])
         bg = (d.median - d.offset_mean)
         return {
-            "pi_mean": torch.ones(Q, 2, dtype=torch.float64), "pi_size": f((Q, 1), 2),
+            "pi_mean": torch.ones(Q, 2, dtype=_DT[0]), "pi_size": f((Q, 1), 2),
             "m_probs": f((K, d.Nt, d.F, Q), 0.5),
             "proximity_loc": f((), 0.5), "proximity_size": f((), 100),
             "lamda_loc": f((Q,), 0.5), "lamda_beta": f((Q,), 100),
@@ -207,7 +222,7 @@ class CosmosOracle:
         values = self.init_values() if values is None else values
         self.params = {}
         for name, v in values.items():
-            u = transform_to(self.constraints[name]).inv(v.to(torch.float64))
+            u = transform_to(self.constraints[name]).inv(v.to(_DT[0]))
             self.params[name] = u.detach().clone().requires_grad_(True)
         return self.params
 
@@ -279,7 +294,7 @@ class CosmosOracle:
     def m_grid(self):
         """(M=2^K, K) table; combo index mi has bit k = m_k."""
         K = self.K
-        return torch.tensor([[(mi >> k) & 1 for k in range(K)] for mi in range(2**K)], dtype=torch.float64)
+        return torch.tensor([[(mi >> k) & 1 for k in range(K)] for mi in range(2**K)], dtype=_DT[0])
 
     def zt_marginal(self, lat, ndx, parts=False):
         """log sum_{z,theta} p(z) p(theta|z) prod_k p(m_k|theta) [p(x_k|theta) p(y_k|theta)]^{m_k}
@@ -291,7 +306,7 @@ class CosmosOracle:
         pi_e = expand_offtarget(lat["pi"])  # (Q, 2, 2)
         pz = pi_e[:, :, on].permute(2, 0, 1)  # (nb, Q, 2[z])
         log_pz = D.Categorical(probs=pz).logits.permute(2, 0, 1)[:, :, None, :]  # (z, nb, 1, C)
-        log_pt = D.Categorical(probs=probs_theta(K)).logits  # (z, theta)
+        log_pt = D.Categorical(probs=probs_theta(K, _DT[0])).logits  # (z, theta)
         pm = probs_m(lat["lamda"], K)  # (Q, 1+K, K)
         size = torch.stack([torch.full_like(lat["proximity"], 2.0), (H / lat["proximity"]) ** 2 - 1], -1)
         joint = log_pz[:, None, None] + log_pt[:, :, None, None, None, None]  # (z, theta, 1, nb, 1, C)
@@ -315,12 +330,12 @@ class CosmosOracle:
         nb, fb = len(ndx), len(fdx)
         s_n = d.Nt / nb
         s = s_n * d.F / fb
-        mask = d.mask[ndx].to(torch.float64)[:, None, None]
+        mask = d.mask[ndx].to(_DT[0])[:, None, None]
         n_, f_ = ndx[:, None], fdx[None, :]
 
         # global sites (cosmos.py:170-184 / 342-368)
         G = D.HalfNormal(_t(pr["gain_std"])).log_prob(lat["gain"]) - g["gain"].log_prob(lat["gain"])
-        G = G + (D.Dirichlet(torch.full((self.Q, 2), 0.5, dtype=torch.float64)).log_prob(lat["pi"])
+        G = G + (D.Dirichlet(torch.full((self.Q, 2), 0.5, dtype=_DT[0])).log_prob(lat["pi"])
                  - g["pi"].log_prob(lat["pi"])).sum()
         G = G + (D.Exponential(_t(pr["lamda_rate"])).log_prob(lat["lamda"]) - g["lamda"].log_prob(lat["lamda"])).sum()
         G = G + D.Exponential(_t(pr["proximity_rate"])).log_prob(lat["proximity"]) - g["proximity"].log_prob(lat["proximity"])
@@ -342,7 +357,7 @@ class CosmosOracle:
 
         # spot sites masked by m_k > 0 (cosmos.py:268-300 / 426-462): model - guide, (K, nb, fb, C)
         T = (D.HalfNormal(_t(pr["height_std"])).log_prob(lat["height"])
-             + AffineBeta(torch.tensor(1.5, dtype=torch.float64), 2.0, pr["width_min"], pr["width_max"]).log_prob(lat["width"])
+             + AffineBeta(torch.tensor(1.5, dtype=_DT[0]), 2.0, pr["width_min"], pr["width_max"]).log_prob(lat["width"])
              - g["height"].log_prob(lat["height"]) - g["width"].log_prob(lat["width"])
              - g["x"].log_prob(lat["x"]) - g["y"].log_prob(lat["y"]))
 

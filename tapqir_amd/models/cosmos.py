@@ -101,10 +101,10 @@ class cosmos(Model):
         return _HipTraceEnumELBO(self, max_plate_nesting=3)
 
     # -- engine / parameters -------------------------------------------------------------------------
-    def _make_engine(self, **kw):
+    def _make_engine(self, engine_cls=None, **kw):
         if self.engine is None:
             kw = {**getattr(self, "_engine_kwargs", {}), **kw}  # AOI sharding: tapqir_amd.parallel.attach
-            self.engine = CosmosEngine(self.data, K=self.K, priors=self.priors, device=self.device, **kw)
+            self.engine = (engine_cls or CosmosEngine)(self.data, K=self.K, priors=self.priors, device=self.device, **kw)
         return self.engine
 
     def init_parameters(self):

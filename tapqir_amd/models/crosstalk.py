@@ -49,10 +49,10 @@ class crosstalk(cosmos):
     def TraceELBO(self, jit=False):
         return _HipTraceEnumELBO(self, max_plate_nesting=2)  # crosstalk.py:457-464
 
-    def _make_engine(self, **kw):
+    def _make_engine(self, engine_cls=None, **kw):
         if self.engine is None:
-            self.engine = CosmosEngine(self.data, K=self.K, priors=self.priors, device=self.device, crosstalk=True,
-                                       **{**getattr(self, "_engine_kwargs", {}), **kw})
+            self.engine = (engine_cls or CosmosEngine)(self.data, K=self.K, priors=self.priors, device=self.device,
+                                                       crosstalk=True, **{**getattr(self, "_engine_kwargs", {}), **kw})
         return self.engine
 
     def init_parameters(self):

@@ -38,17 +38,17 @@ def merge_offsets(samples, weights):
 
 
 class CosmosEngine:
-    def __init__(self, data, K=2, priors=None, device="cuda", eps=None, seed=0, lib=None,
-                 n_offset=0, Nt_global=None, crosstalk=False):
+    # what the library's launch sequence supports (tests/helpers.py derives a checker of the kernels' inline math that
+    # runs the same bodies in plain host loops and switches these off)
+    pipelined_tail = True      # tq_cosmos_step_overlapped: the tail of step t inside the sampling launch of step t+1
+    split_sampling = True      # tq_cosmos_sample_locals_range: sampling split around an in-flight all-reduce
+    lazy_adam_default = True   # tq_cosmos_adam_catchup
+
+    def __init__(self, data, K=2, priors=None, device="cuda", eps=None, seed=0, n_offset=0, Nt_global=None,
+                 crosstalk=False):
         self.device = torch.device(device)
-        self._hostcheck = lib is not None
-        if lib is None:
-            if self.device.type != "cuda":
-                raise HipExtensionError(
-                    "the cosmos SVI step only runs on an AMD GPU through libtapqir_hip.so "
-                    f"(device={device!r} requested); there is no CPU path")
-            lib = _lib.load()
-        self.lib = lib
+        self.lib = self._open_library()
+        lib = self.lib
         # With one dye and one channel the crosstalk model IS cosmos (alpha = [[1]] is a one-component Dirichlet:
         # constant draw, zero log-density, no gradient; the reference's smoke test runs this case,
         # test/test_tapqir.py:27-30): the cosmos kernels run and alpha_mean / alpha_size are inert parameters.
@@ -75,16 +75,7 @@ class CosmosEngine:
         self.mask = data.mask.to(dev, torch.uint8).contiguous()
         # tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the
         # library so that any C caller gets the same layout
-        self.images_il = None
-        if not self._hostcheck:
-            # cosmos: one (P, P) tile per unit (n, f, c); crosstalk: one (C, P, P) tile per AOI-frame (n, f)
-            tiles = self.Nt * self.F * (1 if self.crosstalk else self.C)
-            npix = self.P * self.P * (self.C if self.crosstalk else 1)
-            n_il = int(lib.tq_interleaved_floats_n(tiles, npix))
-            self.images_il = torch.empty(n_il, dtype=f32, device=dev)
-            _lib.check(lib.tq_images_interleave_n(_lib.ptr(self.images), _lib.ptr(self.images_il), tiles, npix,
-                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-                       "tq_images_interleave_n")
+        self.images_il = self._interleaved_images()
         off_s, off_l = merge_offsets(data.offset.samples, data.offset.weights)
         self.offset_samples, self.offset_logits = off_s.to(dev), off_l.to(dev)
         self.O = int(off_s.numel())
@@ -93,13 +84,7 @@ class CosmosEngine:
         if self.O == 1:
             U = self.Nt * self.F * self.C
             self.pixstats = torch.empty(3 * U, dtype=f32, device=dev)
-            if self._hostcheck:
-                lib.hc_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples), _lib.ptr(self.pixstats),
-                                   C.c_int64(U), C.c_int32(self.P))
-            else:
-                _lib.check(lib.tq_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples),
-                                              _lib.ptr(self.pixstats), U, self.P,
-                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tq_image_stats")
+            self._image_stats(U)
         self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps, crosstalk=self.layout_crosstalk)
         n = self.layout.total
         self._params = torch.zeros(n, dtype=f32, device=dev)
@@ -109,11 +94,10 @@ class CosmosEngine:
         # lazy Adam of minibatch steps (include/tapqir_hip.h: tq_cosmos_adam_catchup): per-unit clock of the last update;
         # meaningful only while `_stale` (some unit's local parameters lag behind adam_step).  TAPQIR_AMD_LAZY_ADAM=0:
         # every minibatch step streams the whole buffers through the dense Adam kernel instead
-        self.lazy_adam = (not self._hostcheck) and os.environ.get("TAPQIR_AMD_LAZY_ADAM", "1") != "0"
+        self.lazy_adam = self.lazy_adam_default and os.environ.get("TAPQIR_AMD_LAZY_ADAM", "1") != "0"
         self._last_step = torch.zeros(self.Nt * self.F * self.C, dtype=torch.int32, device=dev)
         self._stale = False
-        gsz = int(lib.hc_globals_size() if self._hostcheck else lib.tq_globals_size())
-        bsz = int(lib.hc_gbase_size() if self._hostcheck else lib.tq_gbase_size())
+        gsz, bsz = self.struct_sizes()
         self.globals = torch.zeros(gsz // 4, dtype=f32, device=dev)
         self.gbase = torch.zeros(bsz // 8, dtype=torch.float64, device=dev)
         self._gsum_buf = torch.zeros(32, dtype=torch.float64, device=dev)  # TQ_GSUM_LEN
@@ -131,6 +115,36 @@ class CosmosEngine:
         # sampling launch (include/tapqir_hip.h: tq_cosmos_step_overlapped); TAPQIR_AMD_OVERLAP=0 turns it off
         self.overlap_tail = os.environ.get("TAPQIR_AMD_OVERLAP", "1") != "0"
         self._tail_args = None  # arguments of the step whose tail is pending
+
+    # -- the library --------------------------------------------------------------------------------
+    def _open_library(self):
+        if self.device.type != "cuda":
+            raise HipExtensionError(
+                "the cosmos SVI step only runs on an AMD GPU through libtapqir_hip.so "
+                f"(device={str(self.device)!r} requested); there is no CPU path")
+        return _lib.load()
+
+    def struct_sizes(self):
+        """(bytes of TqGlobals, bytes of TqGlobalBase)."""
+        return int(self.lib.tq_globals_size()), int(self.lib.tq_gbase_size())
+
+    def _interleaved_images(self):
+        """Tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the library so
+        that any C caller gets the same layout.  cosmos: one (P, P) tile per unit (n, f, c); crosstalk: one (C, P, P)
+        tile per AOI-frame (n, f)."""
+        tiles = self.Nt * self.F * (1 if self.crosstalk else self.C)
+        npix = self.P * self.P * (self.C if self.crosstalk else 1)
+        out = torch.empty(int(self.lib.tq_interleaved_floats_n(tiles, npix)), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.tq_images_interleave_n(_lib.ptr(self.images), _lib.ptr(out), tiles, npix, self._stream()),
+                   "tq_images_interleave_n")
+        return out
+
+    def _image_stats(self, U):
+        _lib.check(self.lib.tq_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples), _lib.ptr(self.pixstats),
+                                           U, self.P, self._stream()), "tq_image_stats")
+
+    def run_probs(self, a):
+        _lib.check(self.lib.tq_cosmos_probs(C.byref(a), self._stream()), "tq_cosmos_probs")
 
     # -- parameter / moment buffers ---------------------------------------------------------------
     # Reading them from outside the step completes deferred work first: the pending tail of a pipelined step and the
@@ -167,10 +181,7 @@ class CosmosEngine:
             self._adam_catchup(a, 1)
 
     def _adam_catchup(self, a, all_units):
-        if self._hostcheck:
-            self.lib.hc_cosmos_adam_catchup(C.byref(a), all_units)
-        else:
-            _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), all_units, self._stream()), "tq_cosmos_adam_catchup")
+        _lib.check(self.lib.tq_cosmos_adam_catchup(C.byref(a), all_units, self._stream()), "tq_cosmos_adam_catchup")
 
     def reset_adam_clock(self, step=0):
         """The buffers were (re)written from outside (initialisation, checkpoint): everything is current at `step`."""
@@ -221,7 +232,9 @@ class CosmosEngine:
     def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None,
                   _for_step=False):
         if not _for_step:
-            self._catch_up_all()  # staged calls from outside read the parameters of arbitrary units
+            # staged calls from outside read the parameters of arbitrary units and overwrite globals / gsum / grad: finish
+            # a pipelined tail or an in-flight all-reduce first, then bring every unit to the current Adam step
+            self.join()
         nb = self.Nt if ndx is None else int(ndx.numel())
         fb = self.F if fdx is None else int(fdx.numel())
         self._workspace(nb, fb)
@@ -299,18 +312,13 @@ class CosmosEngine:
 
     # -- launches ------------------------------------------------------------------------------------
     def _stream(self):
-        if self._hostcheck:
-            return None
         # the raw handle of torch's current stream (torch.cuda.current_stream() builds a Stream object: ~9 us a call,
         # several calls per step)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         return C.c_void_p(torch._C._cuda_getCurrentRawStream(index))
 
     def call(self, name, args):
-        if self._hostcheck:
-            getattr(self.lib, "hc_" + name)(C.byref(args))
-        else:
-            _lib.check(getattr(self.lib, "tq_" + name)(C.byref(args), self._stream()), "tq_" + name)
+        _lib.check(getattr(self.lib, "tq_" + name)(C.byref(args), self._stream()), "tq_" + name)
 
     def step(self, ndx=None, fdx=None, allreduce=None):
         """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``).
@@ -332,7 +340,7 @@ class CosmosEngine:
         else:
             self._catch_up_all()
             a.last_step = None  # full batch: no unit falls behind
-        if allreduce is None and not self._hostcheck:
+        if allreduce is None and self.pipelined_tail:
             self._finish_pending()
             if self.overlap_tail and a.fuse_adam:
                 prev = self._tail_args
@@ -348,7 +356,7 @@ class CosmosEngine:
             if pending is not None and not a.fuse_adam:
                 self._finish_pending()  # a minibatch step samples after the dense Adam of the previous one
                 pending = None
-            if pending is not None and not self._hostcheck:
+            if pending is not None and self.split_sampling:
                 # first half of the local sites while the all-reduce is in flight; the rest in a launch that also
                 # carries the pending step's post-all-reduce tail and this step's global draws
                 nsites = 1 + 4 * self.K
@@ -379,10 +387,7 @@ class CosmosEngine:
     def _tail_reduced(self, a, next_args):
         """Everything of step `a` after the all-reduce (one launch), plus the global draws of `next_args`."""
         nxt = None if next_args is None else C.byref(next_args)
-        if self._hostcheck:
-            self.lib.hc_cosmos_tail_reduced(C.byref(a), nxt)
-        else:
-            _lib.check(self.lib.tq_cosmos_tail_reduced(C.byref(a), nxt, self._stream()), "tq_cosmos_tail_reduced")
+        _lib.check(self.lib.tq_cosmos_tail_reduced(C.byref(a), nxt, self._stream()), "tq_cosmos_tail_reduced")
 
     def _finish_pending(self, next_args=None):
         """Global tail of a step whose all-reduce was left in flight."""

@@ -5,8 +5,6 @@ Posterior read-out of the cosmos model on the device (tapqir/models/cosmos.py:60
 ``(Nt, F, Q, 1+S)`` and ``(K, Nt, F, Q)``; it launches ``tq_cosmos_probs`` (include/tapqir_hip.h).
 """
 
-import ctypes as C
-
 import torch
 
 from tapqir_amd import _lib
@@ -16,9 +14,7 @@ def probs_args(eng, particles, seed, draw=True, gbase_p=None, xy_given=None):
     """Allocate outputs/workspace for ``tq_cosmos_probs`` and fill the argument block."""
     dev, f32 = eng.device, torch.float32
     U = eng.Nt * eng.F * eng.C
-    hc = eng._hostcheck
-    gsz = int(eng.lib.hc_globals_size() if hc else eng.lib.tq_globals_size())
-    bsz = int(eng.lib.hc_gbase_size() if hc else eng.lib.tq_gbase_size())
+    gsz, bsz = eng.struct_sizes()
     ws = {
         "globals_p": torch.zeros(particles * gsz // 4, dtype=f32, device=dev),
         "gbase_p": torch.zeros(particles * bsz // 8, dtype=torch.float64, device=dev) if gbase_p is None else gbase_p,
@@ -37,10 +33,7 @@ def probs_args(eng, particles, seed, draw=True, gbase_p=None, xy_given=None):
 
 
 def run_probs(eng, a):
-    if eng._hostcheck:
-        eng.lib.hc_cosmos_probs(C.byref(a))
-    else:
-        _lib.check(eng.lib.tq_cosmos_probs(C.byref(a), eng._stream()), "tq_cosmos_probs")
+    eng.run_probs(a)
 
 
 def compute_probs(model, particles=50):

@@ -9,7 +9,7 @@ import torch
 from oracle.cosmos import CosmosOracle, OracleData
 from oracle.crosstalk import CrosstalkOracle
 from tapqir_amd import _lib
-from tapqir_amd.models.engine import CosmosEngine
+from tapqir_amd.models.engine import CosmosEngine as HipEngine
 from tapqir_amd.utils.dataset import CosmosDataset
 from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
 
@@ -55,6 +55,49 @@ def load_hostcheck():
     lib.hc_cosmos_tail_reduced.restype = None
     _hc = lib
     return lib
+
+
+class HostCheckEngine(HipEngine):
+    """The engine's host logic (workspace, argument blocks, lazy-Adam clock, sharded step sequence) driving the g++ build
+    of the kernels' inline math on host memory instead of libtapqir_hip.so.  Test-side only: it lets the CPU suite run the
+    parity comparisons and the world-size-2 gloo test without a GPU.  The product class has no such path."""
+
+    pipelined_tail = False     # the host build has the plain stage functions only
+    split_sampling = False
+    lazy_adam_default = False
+
+    def _open_library(self):
+        return load_hostcheck()
+
+    def struct_sizes(self):
+        return int(self.lib.hc_globals_size()), int(self.lib.hc_gbase_size())
+
+    def _interleaved_images(self):
+        return None  # the interleaved layout belongs to the GPU kernels
+
+    def _image_stats(self, U):
+        self.lib.hc_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples), _lib.ptr(self.pixstats),
+                                C.c_int64(U), C.c_int32(self.P))
+
+    def _stream(self):
+        return None
+
+    def call(self, name, args):
+        getattr(self.lib, "hc_" + name)(C.byref(args))
+
+    def _adam_catchup(self, a, all_units):
+        self.lib.hc_cosmos_adam_catchup(C.byref(a), all_units)
+
+    def _tail_reduced(self, a, next_args):
+        self.lib.hc_cosmos_tail_reduced(C.byref(a), None if next_args is None else C.byref(next_args))
+
+    def run_probs(self, a):
+        self.lib.hc_cosmos_probs(C.byref(a))
+
+
+def CosmosEngine(data, lib=None, **kw):
+    """Engine factory of the tests: the HIP engine, or (``lib`` = the loaded host build) its host-check subclass."""
+    return HostCheckEngine(data, **kw) if lib is not None else HipEngine(data, **kw)
 
 
 def make_dataset(N=4, F=6, C=1, P=14, K=2, seed=0, offsets="sim", mask=None):

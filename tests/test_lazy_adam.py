@@ -118,13 +118,13 @@ def test_staged_calls_after_lazy_steps_see_current_parameters():
 def test_lazy_adam_on_the_host_build():
     """The same comparison without a GPU: the kernels' inline code compiled with g++ (tests/hostcheck), lazy against
     dense Adam over mixed minibatch / full-batch steps, and the replay of never-touched units against the closed loop."""
-    from helpers import load_hostcheck
+    from helpers import HostCheckEngine
 
     d = make_dataset(N=4, F=6, K=2, seed=5)
     o = make_oracle(d, 2, perturb=0.2, seed=2)
     engs = []
     for lazy in (False, True):
-        eng = CosmosEngine(d, K=2, device=torch.device("cpu"), seed=11, lib=load_hostcheck())
+        eng = HostCheckEngine(d, K=2, device=torch.device("cpu"), seed=11)
         eng.lazy_adam = lazy
         oracle_to_engine(o, eng)
         engs.append(eng)

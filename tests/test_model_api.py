@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from helpers import CosmosEngine, load_hostcheck
+from helpers import CosmosEngine, HostCheckEngine, load_hostcheck
 from tapqir_amd.exceptions import TapqirFileNotFoundError
 from tapqir_amd.models import Cosmos, Model, cosmos, models
 from tapqir_amd.models.layout import ParamLayout
@@ -71,7 +71,7 @@ def _fit_flow(tmp_path, device, lib):
     m = cosmos(K=2, device=device)
     m.load(tmp_path)
     if lib is not None:
-        m._make_engine(lib=lib)
+        m._make_engine(engine_cls=HostCheckEngine)
     m.init(lr=0.005, nbatch_size=2, fbatch_size=5)
     assert m.nbatch_size == 2 and m.fbatch_size == 5 and m.iter == 0
     m.run(3, progress_bar=lambda r: r)
@@ -84,7 +84,7 @@ def _fit_flow(tmp_path, device, lib):
     m2 = cosmos(K=2, device=device)
     m2.load(tmp_path)
     if lib is not None:
-        m2._make_engine(lib=lib)
+        m2._make_engine(engine_cls=HostCheckEngine)
     m2.init(lr=0.005, nbatch_size=2, fbatch_size=5)
     assert m2.iter == ck["iter"]
     for n, t in ck["params"]["params"].items():
