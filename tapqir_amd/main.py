@@ -270,18 +270,23 @@ def main(
         _write_config(cd)
         typer.echo(f"Initialized Tapqir at {tp}.")
 
-    logger = logging.getLogger("tapqir")
-    logger.setLevel(logging.DEBUG)
-    for h in list(logger.handlers):  # repeated invocations in one process (tests) must not stack handlers
-        logger.removeHandler(h)
+    # the package's modules log under "tapqir_amd.*" (getLogger(__name__)); "tapqir" is kept for code written against the
+    # reference's logger name (main.py:1353-1372)
     ch = logging.StreamHandler(sys.stdout)
     ch.setLevel(logging.INFO)
     ch.setFormatter(logging.Formatter("%(levelname)s - %(message)s"))
-    logger.addHandler(ch)
     fh = logging.FileHandler(tp / "loginfo")
     fh.setLevel(logging.DEBUG)
     fh.setFormatter(logging.Formatter(fmt="%(asctime)s - %(levelname)s - %(message)s", datefmt="%m/%d/%Y %I:%M %p"))
-    logger.addHandler(fh)
+    for name in ("tapqir_amd", "tapqir"):
+        lg = logging.getLogger(name)
+        lg.setLevel(logging.DEBUG)
+        for h in list(lg.handlers):  # repeated invocations in one process (tests) must not stack handlers
+            lg.removeHandler(h)
+            h.close()
+        lg.addHandler(ch)
+        lg.addHandler(fh)
+    logger = logging.getLogger("tapqir_amd")
 
     with open(cfg) as f:
         DEFAULTS.update(yaml.safe_load(f) or {})

@@ -17,13 +17,55 @@ from tapqir_amd.models.engine import DEFAULT_PRIORS, CosmosEngine
 from tapqir_amd.models.model import Model
 
 
-def initial_values(eng, data):
+def data_median(images, collective=None, chunk=1 << 26):
+    """Per-channel median over ALL pixels of ``images (Nt, F, C, P, P)`` = ``CosmosDataset.median``
+    (tapqir/utils/dataset.py:134-138: ``torch.median``, i.e. the lower of the two middle values), computed where the
+    images are (the engine's HBM-resident copy).
+
+    Integer-valued, non-negative images -- every real dataset (glimpse_reader.py:376-378 stores integers) and the
+    simulator (simulate.py:118-122 floors) -- take an exact counting median: a histogram over the integer values, which
+    in an AOI-sharded fit is summed over the ranks (``collective``) so that every rank starts from the median of the whole
+    dataset, whatever the sharding.  Other data use ``torch.median`` of the local pixels."""
+    C = images.shape[2]
+    out = []
+    for c in range(C):
+        x = images[:, :, c].reshape(-1)
+        lo, hi = x.min(), x.max()
+        span = torch.stack([lo, -hi]).double().cpu()
+        if collective is not None:
+            collective.reduce_(span, "min")
+        lo_i, hi_i = int(span[0]), int(-span[1])
+        integral = bool(float(span[0]) >= 0 and -float(span[1]) < (1 << 24))
+        if integral:
+            for s in range(0, x.numel(), chunk):
+                xs = x[s:s + chunk]
+                if not bool((xs == xs.floor()).all()):
+                    integral = False
+                    break
+        if collective is not None:
+            integral = not collective.any(not integral)
+        if not integral:
+            out.append(torch.median(x).double().cpu())
+            continue
+        hist = torch.zeros(hi_i - lo_i + 1, dtype=torch.int64, device=x.device)
+        for s in range(0, x.numel(), chunk):
+            hist += torch.bincount(x[s:s + chunk].to(torch.int64) - lo_i, minlength=hist.numel())
+        hist = hist.cpu()
+        if collective is not None:
+            collective.reduce_(hist, "sum")
+        k = (int(hist.sum()) - 1) // 2  # rank of the lower median
+        out.append(torch.tensor(float(lo_i + int(torch.searchsorted(torch.cumsum(hist, 0), k, right=True))),
+                                dtype=torch.float64))
+    return torch.stack(out)
+
+
+def initial_values(eng, data, collective=None):
     """Constrained initial values, cosmos.py:471-598."""
     K, Nt, F, C = eng.K, eng.Nt, eng.F, eng.C
     Q = C
     f = lambda shape, v: torch.full(shape, float(v), dtype=torch.float64)
-    images = data.images
-    med = torch.stack([torch.median(images[..., c, :, :].reshape(-1)[:50_000_000]) for c in range(C)]).double().cpu()
+    med = data_median(eng.images, collective)
+    # (the reference takes median - offset.mean as it is; a non-positive value has no `positive` pre-image there)
     bg = (med - data.offset.mean).clamp(min=1e-3)
     return {
         "pi_mean": torch.full((Q, 2), 0.5, dtype=torch.float64),  # ones -> softmax -> uniform (Appendix B.5)
@@ -110,7 +152,7 @@ class cosmos(Model):
     def init_parameters(self):
         """cosmos.py:464-598."""
         eng = self._make_engine()
-        eng.layout.set_constrained(eng.params, initial_values(eng, self.data))
+        eng.layout.set_constrained(eng.params, initial_values(eng, self.data, self.collective))
         eng.exp_avg.zero_()
         eng.exp_avg_sq.zero_()
         eng.grad.zero_()
@@ -152,7 +194,7 @@ class cosmos(Model):
         minibatch -ELBO; raises ValueError on a non-finite loss so that ``run``'s recovery path
         (model.py:220-232) works."""
         self.step_async()
-        loss = self.last_loss()
+        loss = self.last_loss()  # the ELBO every rank of a sharded fit reports is the global one: same branch everywhere
         if not math.isfinite(loss):
             raise ValueError(f"Iteration #{getattr(self, 'iter', 0)}. Non-finite loss {loss}")
         return loss

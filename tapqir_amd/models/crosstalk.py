@@ -16,9 +16,9 @@ from tapqir_amd.models.cosmos import _HipTraceEnumELBO, cosmos, initial_values
 from tapqir_amd.models.engine import CosmosEngine
 
 
-def crosstalk_initial_values(eng, data):
+def crosstalk_initial_values(eng, data, collective=None):
     """crosstalk.py:424-455 followed by cosmos._init_parameters."""
-    v = initial_values(eng, data)
+    v = initial_values(eng, data, collective)
     Q, C = eng.C, eng.C
     conc = torch.ones(Q, C, dtype=torch.float64) + 9 * torch.eye(Q, dtype=torch.float64)
     v["alpha_mean"] = conc / conc.sum(-1, keepdim=True)  # stored through the softmax transform (Appendix B.5)
@@ -57,7 +57,7 @@ class crosstalk(cosmos):
 
     def init_parameters(self):
         eng = self._make_engine()
-        eng.layout.set_constrained(eng.params, crosstalk_initial_values(eng, self.data))
+        eng.layout.set_constrained(eng.params, crosstalk_initial_values(eng, self.data, self.collective))
         eng.exp_avg.zero_()
         eng.exp_avg_sq.zero_()
         eng.grad.zero_()

@@ -14,6 +14,7 @@ import torch
 
 from tapqir_amd.exceptions import CudaOutOfMemoryError, TapqirFileNotFoundError
 from tapqir_amd.utils.dataset import load
+from tapqir_amd.utils.safe_load import load_tpqr
 
 logger = logging.getLogger(__name__)
 
@@ -65,6 +66,8 @@ class Model:
         self.path = None
         self.run_path = None
         self.engine = None
+        self.collective = None  # tapqir_amd.parallel.attach: blocking collectives of an AOI-sharded fit
+        self.stats_path = None  # where compute_stats writes (default: self.path)
         self.to(device, dtype)
 
     def to(self, device: str, dtype: str = "double") -> None:
@@ -86,7 +89,7 @@ class Model:
         logger.debug(f"Loaded data from {self.path / 'data.tpqr'}")
         if not data_only:
             try:
-                self.params = torch.load(self.path / f"{self.name}_params.tpqr", weights_only=False)
+                self.params = load_tpqr(self.path / f"{self.name}_params.tpqr")
             except FileNotFoundError:
                 raise TapqirFileNotFoundError("parameter", self.path / f"{self.name}_params.tpqr")
             try:
@@ -171,6 +174,8 @@ class Model:
                     # load last checkpoint, change rng seed (model.py:220-232)
                     self.init(lr=self.lr, nbatch_size=self.nbatch_size, fbatch_size=self.fbatch_size)
                     new_seed = random.randint(0, 100)
+                    if self.collective is not None:  # every rank must draw the same global latents: rank 0 decides
+                        new_seed = self.collective.broadcast_int(new_seed)
                     self.set_rng_seed(new_seed)
                     logger.warning(f"Iteration #{self.iter} restarting with a new seed: {new_seed}.")
                 except RuntimeError as err:
@@ -193,11 +198,16 @@ class Model:
     def save_checkpoint(self, writer=None):
         eng = self.engine
         eng.join()
-        # save only if no NaN values (model.py:245-250)
-        if not bool(torch.isfinite(eng.params).all()):
+        # save only if no NaN values (model.py:245-250).  In an AOI-sharded fit the ranks agree on the outcome, so that
+        # all of them roll back to their checkpoints together (the local parameters live on one rank only)
+        bad = not bool(torch.isfinite(eng.params).all())
+        if self.collective is not None:
+            bad = self.collective.any(bad)
+        if bad:
             for k, v in self.named_params().items():
                 if not bool(torch.isfinite(v).all()):
                     raise ValueError("Iteration #{}. Detected NaN values in {}".format(self.iter, k))
+            raise ValueError("Iteration #{}. Detected NaN values on another rank".format(self.iter))
         # (without a tensorboard writer only the convergence parameters -- globals -- are needed)
         cparams = eng.layout.constrained(eng.params, None if writer is not None else set(self.conv_params))
         for name in self.conv_params:
@@ -223,7 +233,7 @@ class Model:
                     "iter": self.iter,
                     "params": self._param_store_state(),
                     "optimizer": self._optim_state(),
-                    "rolling": dict(self._rolling),
+                    "rolling": {k: list(v) for k, v in self._rolling.items()},  # model.py:279 stores the deques
                     "convergence_status": self.converged,
                 },
                 self.run_path / f"{self.name}_model.tpqr",
@@ -270,7 +280,7 @@ class Model:
             raise TapqirFileNotFoundError("model", f"{self.name}_model.tpqr")
         model_path = path / f"{self.name}_model.tpqr"
         try:
-            checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+            checkpoint = load_tpqr(model_path, map_location="cpu")
         except FileNotFoundError:
             raise TapqirFileNotFoundError("model", model_path)
         if self.engine is None:
@@ -281,7 +291,8 @@ class Model:
             views[n].copy_(t.reshape(views[n].shape).to(eng.params.dtype))
         if not param_only:
             self.converged = checkpoint["convergence_status"]
-            self._rolling = defaultdict(lambda: deque([], maxlen=100), checkpoint["rolling"])
+            self._rolling = defaultdict(lambda: deque([], maxlen=100),
+                                        {k: deque(v, maxlen=100) for k, v in checkpoint["rolling"].items()})
             self.iter = checkpoint["iter"]
             m, v = eng.named("exp_avg"), eng.named("exp_avg_sq")
             step = 0
@@ -300,7 +311,10 @@ class Model:
         from tapqir_amd.utils.stats import save_stats
 
         try:
-            save_stats(self, self.path, CI=CI, save_matlab=save_matlab)
+            out = self.stats_path or self.path
+            if out is not None:
+                Path(out).mkdir(parents=True, exist_ok=True)
+            save_stats(self, out, CI=CI, save_matlab=save_matlab)
         except RuntimeError as err:
             if _is_oom(err):
                 raise CudaOutOfMemoryError()

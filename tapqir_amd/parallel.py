@@ -31,11 +31,48 @@ def shard_bounds(Nt, rank, world):
 def shard_dataset(data, rank, world):
     """The AOIs of ``rank`` as a CosmosDataset + (n_offset, Nt_global) for CosmosEngine."""
     lo, hi = shard_bounds(data.images.shape[0], rank, world)
+    labels = None
+    if data.labels is not None:
+        # labels hold one row per ON-TARGET AOI, in AOI order (dataset.py: labels[: N]; simulate.py:124-131)
+        on = data.is_ontarget.cpu()
+        row = torch.cumsum(on.long(), 0) - 1
+        labels = data.labels[row[lo:hi][on[lo:hi]].numpy()]
     sub = CosmosDataset(
-        data.images[lo:hi], data.xy[lo:hi], data.is_ontarget[lo:hi], mask=data.mask[lo:hi], labels=None,
+        data.images[lo:hi], data.xy[lo:hi], data.is_ontarget[lo:hi], mask=data.mask[lo:hi], labels=labels,
         offset_samples=data.offset.samples, offset_weights=data.offset.weights, device=data.device,
         name=data.name, channels=data.channels)
     return sub, lo, data.images.shape[0]
+
+
+class Collective:
+    """The few blocking collectives a sharded fit needs OUTSIDE the step (initialisation from global data statistics,
+    agreeing on the NaN-recovery branch and its new seed): tiny tensors, a handful of calls per fit."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def _dev(self, t):
+        # the "nccl" backend (= RCCL) moves device tensors only
+        return t.cuda() if self.dist.get_backend(self.group) == "nccl" and not t.is_cuda else t
+
+    def reduce_(self, t, op="sum"):
+        ops = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}
+        d = self._dev(t)
+        self.dist.all_reduce(d, op=ops[op], group=self.group)
+        if d is not t:
+            t.copy_(d)
+        return t
+
+    def any(self, flag: bool) -> bool:
+        return bool(self.reduce_(torch.tensor([1.0 if flag else 0.0]), "max")[0] > 0)
+
+    def broadcast_int(self, value: int, src: int = 0) -> int:
+        t = self._dev(torch.tensor([int(value)], dtype=torch.int64))
+        self.dist.broadcast(t, src=src, group=self.group)
+        return int(t[0])
 
 
 def make_allreduce(group=None, async_op=False):
@@ -64,6 +101,9 @@ def attach(model, group=None, async_op=True):
     model.engine = None
     model._engine_kwargs = dict(n_offset=lo, Nt_global=Nt_global)
     model.allreduce = make_allreduce(group, async_op=async_op)
+    model.collective = Collective(group)
     if world > 1 and model.run_path is not None:
+        # every rank keeps its own checkpoint AND writes its own statistics (its AOIs only): no file is shared
         model.run_path = model.run_path / f"rank{rank}"
+        model.stats_path = model.path / f"rank{rank}"
     return model

@@ -139,4 +139,6 @@ def load(path, device=torch.device("cpu")):
     source = Path(path) / DATA_FILE
     if not source.is_file():
         raise TapqirFileNotFoundError("data", source)
-    return CosmosDataset(**torch.load(source, weights_only=False), device=device)
+    from tapqir_amd.utils.safe_load import load_tpqr
+
+    return CosmosDataset(**load_tpqr(source), device=device)

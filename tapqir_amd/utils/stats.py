@@ -124,7 +124,10 @@ def save_stats(model, path, CI=0.95, save_matlab=False):
 
         on = data.is_ontarget.cpu()
         pred = (ci_stats["z_map"][on] > 0).numpy().ravel().astype(int)
-        true = np.asarray(data.labels["z"]).ravel().astype(int)
+        # labels of the on-target AOIs only (stats.py:196: labels["z"][: model.data.N]; read_glimpse stacks the
+        # off-target labels behind them when both label files are given)
+        true_z = np.asarray(data.labels["z"])[: data.N]
+        true = true_z.ravel().astype(int)
         with np.errstate(divide="ignore", invalid="ignore"):
             summary.loc["MCC", "Mean"] = matthews_corrcoef(true, pred)
         summary.loc["Recall", "Mean"] = recall_score(true, pred, zero_division=0)
@@ -134,7 +137,7 @@ def save_stats(model, path, CI=0.95, save_matlab=False):
             summary.loc[k, "Mean"] = v
         # z_map at the truly specific AOI-frames: median and highest-density interval (stats.py:214-226)
         zmap_on = (ci_stats["z_map"][on] > 0).long()
-        samples = torch.masked_select(zmap_on, torch.from_numpy(np.asarray(data.labels["z"])) > 0)
+        samples = torch.masked_select(zmap_on, torch.from_numpy(true_z) > 0)
         if samples.numel():
             lo, hi = hpdi(samples, CI)
             summary.loc["p(specific)", "Mean"] = float(quantile(samples, 0.5))

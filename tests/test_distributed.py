@@ -109,3 +109,89 @@ def test_shard_bounds_cover_everything():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _model_worker(rank, world, port, q, tmp):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+
+    from helpers import HostCheckEngine
+    from tapqir_amd.models import cosmos
+    from tapqir_amd.models.cosmos import data_median
+    from tapqir_amd.parallel import attach
+
+    m = cosmos(K=2, device="cpu")
+    m.load(tmp)
+    full_labels = np.asarray(m.data.labels["z"]).copy()
+    full_median = data_median(m.data.images)
+    attach(m)
+    out = {"rank": rank}
+    # labels follow the shard (on-target AOIs are the first half of 6: rank 0 holds 3 labelled AOIs, rank 1 none)
+    lo, hi = (0, 3) if rank == 0 else (3, 6)
+    out["labels_ok"] = bool(np.array_equal(np.asarray(m.data.labels["z"]), full_labels[lo:min(hi, 3)]))
+    m._make_engine(engine_cls=HostCheckEngine)
+    m.init(lr=0.005, nbatch_size=3, fbatch_size=5)
+    # every rank initialises from the median of the WHOLE dataset (counting median summed over ranks)
+    bml = m.engine.layout.constrained(m.engine.params)["background_mean_loc"]
+    out["median_ok"] = bool(torch.allclose(bml.double().cpu(), (full_median - m.data.offset.mean).expand_as(bml), rtol=1e-6))
+    m.run(2, progress_bar=lambda r: r)
+    out["stats_dir"] = str(m.stats_path)
+    # a NaN on ONE rank makes EVERY rank take the recovery branch (model.py:220-232), with one common new seed
+    if rank == 1:
+        m.engine.params[0] = float("nan")
+    m.iter_loss = 0.0
+    try:
+        m.save_checkpoint()
+        out["raised"] = False
+    except ValueError:
+        out["raised"] = True
+    import random
+
+    random.seed(100 + rank)  # the ranks' own draws differ: 0 decides
+    out["seed"] = m.collective.broadcast_int(random.randint(0, 100))
+    m2 = cosmos(K=2, device="cpu")
+    m2.load(tmp)
+    attach(m2)
+    m2._make_engine(engine_cls=HostCheckEngine)
+    m2.init(lr=0.005, nbatch_size=3, fbatch_size=5)
+    m2.compute_stats()
+    out["stats_files"] = sorted(os.listdir(m2.stats_path))
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_model_ranks_stay_in_step(tmp_path):
+    """Model-level behaviour of an AOI-sharded fit (tapqir_amd.parallel.attach): global median at initialisation, labels
+    sliced with the shard, NaN recovery and reseeding agreed between the ranks, per-rank output files."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tapqir_amd.utils.dataset import save
+    from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+    d = simulate(2, 6, 5, 1, 14, 0, TEST_PARAMS)
+    d.images[:3] += 40.0  # the two shards have different local medians
+    save(d, tmp_path)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 101) % 2000
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(o["labels_ok"] and o["median_ok"] and o["raised"] for o in outs), outs
+    assert outs[0]["seed"] == outs[1]["seed"]
+    assert outs[0]["stats_dir"] != outs[1]["stats_dir"]
+    for o in outs:
+        assert "cosmos_params.tpqr" in o["stats_files"] and "cosmos_summary.csv" in o["stats_files"]

@@ -1,0 +1,229 @@
+"""
+The BASELINE.json configs at the size ONE GPU holds of them (c2 = 400 x 1000; c3's shard 400 x 4000; c4 = crosstalk
+400 x 1000 x 2 channels; c5's shard K=3 P=20 250 x 2000), where the dense CPU oracle cannot run the whole batch:
+
+  * ORACLE SPOT CHECK: after one staged full-batch evaluation with the device's own guide draws, 8 random AOIs x 8 random
+    frames are handed to the oracle (their images, parameters and latent draws): per-combination log-likelihoods
+    and the gradients of every local variational parameter must agree to 1e-4 (north_star's tolerance);
+  * additivity of the cross-unit sums over AOI shards with identical draws (what the data-parallel all-reduce relies on);
+  * the two pixel-kernel mappings (packed lane-per-unit on the interleaved copy vs 16 lanes per unit on LDS tiles)
+    agree on every unit;
+  * exchangeability of the spots;
+  * optimisation steps improve the ELBO and keep everything finite.
+"""
+
+import pytest
+import torch
+
+from helpers import EPS32, oracle_grads, rel_err
+from oracle.cosmos import CosmosOracle, OracleData
+from oracle.crosstalk import CrosstalkOracle
+from tapqir_amd.models.cosmos import initial_values
+from tapqir_amd.models.crosstalk import crosstalk_initial_values
+from tapqir_amd.models.engine import CosmosEngine
+from tapqir_amd.parallel import shard_dataset
+from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+pytestmark = pytest.mark.gpu
+
+#        id           model       K  P   AOIs frames C
+SHARDS = [("c2", "cosmos", 2, 14, 400, 1000, 1),
+          ("c3_shard", "cosmos", 2, 14, 400, 4000, 1),
+          ("c4", "crosstalk", 2, 14, 400, 1000, 2),
+          ("c5_shard", "cosmos", 3, 20, 250, 2000, 1)]
+
+
+class Shard:
+    def __init__(self, tag, model, K, P, N, F, C):
+        self.tag, self.xt, self.K, self.P, self.N, self.F, self.C = tag, model == "crosstalk", K, P, N, F, C
+
+        class M:
+            pass
+
+        M.K, M.device = K, torch.device("cuda", 0)
+        params = dict(TEST_PARAMS, alpha=[[0.9, 0.1], [0.2, 0.8]]) if self.xt else TEST_PARAMS
+        self.data = simulate(M, N, F, C, P, seed=5, params=params)
+
+    def engine(self, data=None, **kw):
+        data = self.data if data is None else data
+        eng = CosmosEngine(data, K=self.K, device="cuda:0", seed=21, crosstalk=self.xt, **kw)
+        eng.layout.set_constrained(eng.params, (crosstalk_initial_values if self.xt else initial_values)(eng, data))
+        return eng
+
+    def perturb(self, eng, seed=0, scale=0.3):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        v = eng.named("params")
+        for n in ("h_loc", "w_mean", "x_mean", "y_mean", "m_probs", "b_loc", "size", "w_size", "h_beta"):
+            v[n].add_(scale * torch.randn(v[n].shape, generator=g, device="cuda"))
+
+
+@pytest.fixture(scope="module", params=SHARDS, ids=[s[0] for s in SHARDS])
+def shard(request):
+    s = Shard(*request.param)
+    yield s
+    del s
+    torch.cuda.empty_cache()
+
+
+def _stages(eng, draw=True):
+    a = eng.make_args(draw_globals=draw)
+    for st in ("cosmos_sample_globals", "cosmos_sample_locals", "cosmos_elbo_grads", "cosmos_globals_grad"):
+        eng.call(st, a)
+    torch.cuda.synchronize()
+    return eng.gsum.clone(), float(eng.elbo_out[0])
+
+
+def _oracle_for_units(s, eng, nd, fd):
+    """Oracle over the AOIs `nd` x frames `fd` with the engine's parameters and its latent draws of those units."""
+    d, K, C = s.data, s.K, s.C
+    img = d.images[nd][:, fd]
+    od = OracleData(img, d.xy[nd][:, fd], d.is_ontarget[nd], d.offset.samples.cpu(), d.offset.weights.cpu())
+    o = (CrosstalkOracle if s.xt else CosmosOracle)(od, K=K, eps=EPS32)
+    o.init_parameters()
+    views = eng.named("params")
+    for name, u in o.params.items():
+        v = views[name].detach().cpu().double()
+        if v.dim() == 4:  # (K, Nt, F, Q)
+            v = v[:, nd][:, :, fd]
+        elif v.dim() == 3 and v.shape[1] == 1:  # (Nt, 1, C)
+            v = v[nd]
+        elif v.dim() == 3:  # (Nt, F, C)
+            v = v[nd][:, fd]
+        u.data = v.reshape(u.shape).clone()
+    lat = eng.lat.detach().cpu().double().view(1 + 4 * K, s.N, s.F, C)[:, nd][:, :, fd]
+    g = eng.globals.detach().cpu().double()
+    lat32 = {"background": lat[0], "height": lat[1:1 + K], "width": lat[1 + K:1 + 2 * K],
+             "x": lat[1 + 2 * K:1 + 3 * K], "y": lat[1 + 3 * K:1 + 4 * K],
+             "gain": g[0].clone(), "proximity": g[1].clone(), "lamda": g[5:5 + C].clone(),
+             "pi": torch.stack([1 - g[9:9 + C], g[9:9 + C]], -1)}
+    if s.xt:
+        lat32["alpha"] = g[21:25].clone().view(2, 2)
+    ar_n, ar_f = torch.arange(len(nd)), torch.arange(len(fd))
+    with torch.no_grad():
+        base = o.base_draws(lat32, o._guide_dists(o.constrained(o.params), ar_n, ar_f))
+    return o, base, ar_n, ar_f
+
+
+def test_sampled_units_match_the_oracle(shard):
+    s = shard
+    eng = s.engine()
+    s.perturb(eng)
+    _stages(eng)
+    K, M, C = s.K, 1 << s.K, s.C
+    g = torch.Generator().manual_seed(3)
+    # on-target AOIs are the first half: take 4 of each kind
+    nd = torch.cat([torch.randperm(s.N // 2, generator=g)[:4], s.N // 2 + torch.randperm(s.N - s.N // 2, generator=g)[:4]])
+    fd = torch.randperm(s.F, generator=g)[:8]
+    o, base, ar_n, ar_f = _oracle_for_units(s, eng, nd, fd)
+    _, g_o = oracle_grads(o, ar_n, ar_f, base)
+    # ---- log-likelihood rows ----
+    ll_k = eng.pix[: M * s.N * s.F * C].view(M, s.N, s.F, C).cpu().double()[:, nd][:, :, fd]
+    ll_o = o.last_terms["ll"].detach()
+    if s.xt:
+        # the kernel stores, per dye q, the likelihood marginalised over the OTHER dye's guide distribution:
+        # LL_q(m_q) = sum_{m_-q} q(m_-q) ll_joint(m_q, m_-q); joint index bit (q K + k) = m_qk
+        p = torch.sigmoid(o.params["m_probs"].detach())  # (K, nb, fb, Q)
+        qm = []
+        for q in range(2):
+            w = torch.ones(M, len(nd), len(fd), dtype=torch.float64)
+            for k in range(K):
+                bit = torch.tensor([(mi >> k) & 1 for mi in range(M)], dtype=torch.float64)[:, None, None]
+                w = w * (bit * p[k, :, :, q] + (1 - bit) * (1 - p[k, :, :, q]))
+            qm.append(w)
+        llj = ll_o.view(M, M, len(nd), len(fd))  # [m_1][m_0] (dye 1 = high bits)
+        marg = torch.stack([(llj * qm[1][:, None]).sum(0), (llj * qm[0][None]).sum(1)], -1)  # (M, nb, fb, Q)
+        assert rel_err(ll_k, marg) < 1e-5
+    else:
+        assert rel_err(ll_k, ll_o) < 1e-5
+    # ---- gradients of the local variational parameters of the sampled units ----
+    gv = eng.named("grad")
+    worst = {}
+    for name, ref in g_o.items():
+        v = gv[name].detach().cpu().double()
+        if v.dim() == 4:
+            got = v[:, nd][:, :, fd]
+        elif v.dim() == 3 and v.shape[1] != 1:
+            got = v[nd][:, fd]
+        else:
+            continue  # per-AOI and global parameters sum over units outside the sample
+        worst[name] = rel_err(got.reshape(ref.shape), ref)
+    assert len(worst) == 10 and max(worst.values()) < 1e-4, worst
+
+
+def test_elbo_is_additive_over_aoi_shards(shard):
+    s = shard
+    full = s.engine()
+    gs_full, _ = _stages(full)
+    parts = []
+    B_full = s.N * s.F * s.C
+    for r in range(2):
+        sub, off, Ntg = shard_dataset(s.data, r, 2)
+        eng = s.engine(sub, n_offset=off, Nt_global=Ntg)
+        fv, sv = full.named("params"), eng.named("params")
+        hi = off + sub.images.shape[0]
+        for n in sv:
+            sv[n].copy_(fv[n][:, off:hi] if sv[n].dim() == 4 else (fv[n][off:hi] if sv[n].dim() == 3 else fv[n]))
+        gs, _ = _stages(eng)
+        parts.append(gs)
+        B = sub.images.shape[0] * s.F * s.C
+        lo = off * s.F * s.C
+        assert torch.equal(eng.lat.view(-1, B)[:, :1000], full.lat.view(-1, B_full)[:, lo:lo + 1000])  # global-id RNG keys
+        del eng
+    total = torch.stack(parts).sum(0)
+    assert torch.allclose(total, gs_full, rtol=2e-6, atol=5e-2), (total, gs_full)
+    assert abs(float(total[2]) - float(gs_full[2])) <= 1e-7 * abs(float(gs_full[2]))
+
+
+def test_pixel_kernels_agree(shard):
+    s = shard
+    outs = []
+    for il in (1, 1 << 30):
+        eng = s.engine()
+        eng.il_min_units = il
+        _stages(eng)
+        outs.append(eng.pix.view(-1, s.N * s.F * s.C).clone())
+        del eng
+    a, b = outs
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = b.abs().amax(1, keepdim=True).clamp(min=1e-20)
+    assert float(((a - b).abs() / scale).max()) < 5e-5
+    M = 1 << s.K
+    assert torch.allclose(a[:M].double().sum(1), b[:M].double().sum(1), rtol=1e-7)
+
+
+def test_spot_exchangeability(shard):
+    s = shard
+    K, M = s.K, 1 << s.K
+    eng = s.engine()
+    s.perturb(eng, seed=1)
+    _stages(eng)
+    B = s.N * s.F * s.C
+    lat0 = eng.lat.view(-1, B).clone()
+    ll0 = eng.pix.view(-1, B)[:M].clone()
+    # swap spot 0 <-> spot 1: latent draws and (crosstalk marginals weigh the other dye's combinations) q(m)
+    lat = eng.lat.view(-1, B)
+    for base in (1, 1 + K, 1 + 2 * K, 1 + 3 * K):  # rows h[k] | w[k] | x[k] | y[k]
+        lat[[base, base + 1]] = lat0[[base + 1, base]]
+    mp = eng.named("params")["m_probs"]
+    mp[[0, 1]] = mp[[1, 0]].clone()
+    a = eng.make_args(draw_globals=False)
+    a.draw_locals = 0
+    eng.call("cosmos_elbo_grads", a)
+    torch.cuda.synchronize()
+    ll1 = eng.pix.view(-1, B)[:M]
+    perm = [(mi & ~3) | ((mi & 1) << 1) | ((mi >> 1) & 1) for mi in range(M)]  # bits 0 and 1 of the combination swapped
+    assert torch.allclose(ll1, ll0[perm], rtol=2e-6, atol=1e-3)
+
+
+def test_steps_improve_the_elbo_and_stay_finite(shard):
+    eng = shard.engine()
+    elbos = []
+    for it in range(30):
+        eng.step()
+        if it % 10 == 9 or it == 0:
+            eng.join()
+            torch.cuda.synchronize()
+            elbos.append(float(eng.elbo_out[0]))
+    eng.join()
+    assert torch.isfinite(eng.params).all() and torch.isfinite(eng.exp_avg_sq).all()
+    assert elbos[-1] > elbos[0], elbos

@@ -191,3 +191,61 @@ def test_parallel_attach_single_rank_group(tmp_path):
         assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
     finally:
         dist.destroy_process_group()
+
+
+def test_data_median_is_the_full_data_median():
+    """Initial background = median of ALL pixels (dataset.py:134-138), not of the head of the buffer: a dataset whose
+    first AOIs are bright must not shift it; the counting median of integer data equals torch.median exactly."""
+    from tapqir_amd.models.cosmos import data_median
+
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(100, 400, (6, 5, 2, 4, 4), generator=g).float()
+    img[:2] += 5000.0  # bright head
+    want = torch.stack([torch.median(img[:, :, c]) for c in range(2)]).double()
+    assert torch.equal(data_median(img), want)
+    assert torch.equal(data_median(img, chunk=37), want)
+    # non-integer data: plain torch.median
+    imf = img + 0.25
+    assert torch.equal(data_median(imf), torch.stack([torch.median(imf[:, :, c]) for c in range(2)]).double())
+    # even number of pixels: the LOWER middle value, as torch.median
+    ev = torch.tensor([1.0, 2.0, 3.0, 4.0]).reshape(1, 1, 1, 2, 2)
+    assert float(data_median(ev)[0]) == 2.0
+
+
+def test_restricted_loader_refuses_foreign_classes(tmp_path):
+    """.tpqr files are read with torch.load(weights_only=True) + an allow-list; a pickle that names any other class is
+    refused instead of executed."""
+    import pickle
+
+    from tapqir_amd.utils.safe_load import load_tpqr
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("executed code from the file",))
+
+    torch.save({"images": torch.zeros(1), "x": Evil()}, tmp_path / "bad.tpqr")
+    with pytest.raises(pickle.UnpicklingError):
+        load_tpqr(tmp_path / "bad.tpqr")
+    import collections
+    torch.save({"rolling": {"a": collections.deque([1.0, 2.0], maxlen=100)}}, tmp_path / "ref_style.tpqr")
+    with pytest.raises(pickle.UnpicklingError, match="TAPQIR_AMD_TRUST_FILES"):
+        load_tpqr(tmp_path / "ref_style.tpqr")
+
+
+def test_stats_with_on_and_off_target_labels(tmp_path):
+    """read_glimpse stacks off-target labels behind the on-target ones (Nt rows); the classification statistics use the
+    first N rows (stats.py:196, 217)."""
+    import numpy as np
+
+    d = simulate(2, 4, 6, 1, 14, 0, TEST_PARAMS)
+    off = np.zeros((2, 6, 1), dtype=d.labels.dtype)
+    d.labels = np.concatenate([d.labels, off], 0)
+    assert d.labels.shape[0] == d.Nt
+    save(d, tmp_path)
+    m = cosmos(K=2, device="cpu")
+    m.load(tmp_path)
+    m._make_engine(engine_cls=HostCheckEngine)
+    m.init(lr=0.005, nbatch_size=4, fbatch_size=6)
+    m.run(2, progress_bar=lambda r: r)
+    m.compute_stats()
+    assert "MCC" in m.summary.index and (tmp_path / "cosmos_summary.csv").is_file()
