@@ -202,7 +202,10 @@ typedef struct {
   float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K]
                                                    (crosstalk: 1+Q more rows: ell_excess, g_alpha[Q]) */
   float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */
-  float* blk_part;             /* [nblk][3+3Q]     per-workgroup partial sums (crosstalk: 3+3Q+Q*Q) */
+  float* blk_part;             /* tq_cosmos_blk_floats() floats: per-workgroup partial sums, [nblk][3+3Q] (crosstalk:
+                                                   3+3Q+Q*Q), or -- full-batch steps run by tq_cosmos_step /
+                                                   tq_cosmos_step_overlapped, whose workgroups are AOI-aligned --
+                                                   [Nt][chunks][8 + 3+3Q(+Q*Q)] with the per-AOI frame sums in front */
   double* gsum;                /* [TQ_GSUM_LEN]    cross-unit sums: d/d gain, d/d cs, ELBO, (d/d rho, a, c)[Q] in the
                                                    first 3+3Q entries (the part a data-parallel host
                                                    all-reduces); the tail is scratch of the library */
@@ -245,7 +248,8 @@ typedef struct {
 
 int64_t tq_globals_size(void);
 int64_t tq_gbase_size(void);
-int64_t tq_cosmos_nblk(int64_t B);              /* rows of blk_part */
+int64_t tq_cosmos_nblk(int64_t B);              /* rows of blk_part (flat layout) */
+int64_t tq_cosmos_blk_floats(int32_t Nt, int32_t F, int32_t C, int32_t crosstalk, int64_t B);  /* floats blk_part must hold */
 int64_t tq_cosmos_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K);
 int64_t tq_crosstalk_param_count(int32_t Nt, int32_t F, int32_t C, int32_t K);  /* + alpha_mean, alpha_size */
 
@@ -282,6 +286,7 @@ int tq_cosmos_adam_catchup(const tq_cosmos_args* a, int32_t all_units, void* str
  * reading elbo_out / the per-AOI and global parameters.  prev == NULL: nothing pending (first step). */
 int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
 int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
+
 /* AOI-sharded runs: everything that follows the all-reduce of gsum (tq_cosmos_globals_grad + tq_cosmos_adam) in one
  * single-workgroup launch, plus -- if `next` is given (full-batch steps) -- the global draws of the next step
  * (tq_cosmos_sample_globals(next)), which need the global parameters this call updates. */

@@ -116,6 +116,7 @@ EXPORTS = [
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
+    "tq_cosmos_blk_floats",
     "tq_cosmos_probs", "tq_glimpse_extract",
 ]
 
@@ -165,6 +166,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int
+    lib.tq_cosmos_blk_floats.argtypes = [C.c_int32] * 4 + [C.c_int64]
+    lib.tq_cosmos_blk_floats.restype = C.c_int64
     for name in ("tq_cosmos_step_overlapped", "tq_cosmos_tail_reduced"):
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.POINTER(CosmosArgs), C.c_void_p]

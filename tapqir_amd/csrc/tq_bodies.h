@@ -122,8 +122,12 @@ TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, floa
 
 // ---- per-unit ELBO terms and gradients --------------------------------------------------------------------
 // part[] receives this unit's contribution to the cross-unit sums (layout TQ_GS_*).
-template <int K>
-TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
+// aoi2 != nullptr: the unit's d/d(background_mean_loc, background_std_loc) partials are returned there instead of being
+// written to a.aoi_part (the fused step kernel sums them per workgroup).
+// LATE_MOMENTS: the Adam moments are loaded after the gradient arithmetic instead of ahead of it (the fused step kernel
+// runs at twice the occupancy of tq_unit_kernel and cannot afford the 4K+... registers that holding them costs).
+template <int K, bool LATE_MOMENTS = false>
+TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* aoi2 = nullptr) {
   constexpr int M = 1 << K;
   constexpr int NL = TQ_NLOCAL(K);
   const int64_t B = tq_batch_units(a), U = tq_num_units(a);
@@ -182,7 +186,7 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
 
   // the Adam moments of the fused update are requested before the arithmetic below so that they arrive during it
   float m_old[NL], v_old[NL];
-  if (a.fuse_adam) {
+  if (a.fuse_adam && !LATE_MOMENTS) {
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
       m_old[r] = a.exp_avg[(int64_t)r * U + ix.u];
@@ -194,6 +198,13 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
   tq_cosmos_unit<K>(in, G, C, &out);
 
   if (a.fuse_adam) {
+    if (LATE_MOMENTS) {
+#pragma unroll
+      for (int r = 0; r < NL; ++r) {
+        m_old[r] = a.exp_avg[(int64_t)r * U + ix.u];
+        v_old[r] = a.exp_avg_sq[(int64_t)r * U + ix.u];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < NL; ++r)
       tq_adam_apply_given(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r], m_old[r], v_old[r]);
@@ -202,8 +213,13 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part) {
 #pragma unroll
     for (int r = 0; r < NL; ++r) a.grad[(int64_t)r * U + ix.u] = masked ? 0.0f : out.g[r];
   }
-  a.aoi_part[i] = masked ? 0.0f : out.g_bml;
-  a.aoi_part[B + i] = masked ? 0.0f : out.g_bsl;
+  if (aoi2) {
+    aoi2[0] = masked ? 0.0f : out.g_bml;
+    aoi2[1] = masked ? 0.0f : out.g_bsl;
+  } else {
+    a.aoi_part[i] = masked ? 0.0f : out.g_bml;
+    a.aoi_part[B + i] = masked ? 0.0f : out.g_bsl;
+  }
 
   const int nq = tq_num_gsum(a);
   for (int j = 0; j < nq; ++j) part[j] = 0.0f;

@@ -9,6 +9,8 @@
 // a single-workgroup fp64 finish; no float atomics.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "tq_bodies.h"
 
 void tq_set_error(const char* msg);
@@ -208,6 +210,124 @@ __global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_ar
   }
 }
 
+// =============================================================================================================
+// AOI-aligned per-unit kernel of full-batch steps (tq_cosmos_step_overlapped / tq_cosmos_step).
+//
+// Grid: x = chunks of 256 units within one AOI (the units (f, c) of AOI n are contiguous), y = AOI.  A workgroup
+// therefore belongs to ONE AOI and its row of partial sums can carry, next to the cross-unit sums, the frame sums of
+// d/d(background_mean_loc, background_std_loc) of that AOI: the single-workgroup tail adds the few rows of an AOI
+// itself, so there is no per-AOI kernel (5 us + a launch boundary at 400 000 units) and no aoi_part round trip
+// (16 B per unit).  Row layout: [2 * TQ_MAXQ per-channel AOI partials][nq cross-unit sums]; the fixed offset keeps
+// every register-array index a compile-time constant.
+// =============================================================================================================
+#define TQ_ROWS_AOICOL (2 * TQ_MAXQ)
+#define TQ_ROWS_MAXCOL (TQ_ROWS_AOICOL + TQ_MAX_NGSUM)
+
+// (host) does this step use the AOI-aligned layout?  TAPQIR_AMD_ROWS=0 keeps the flat layout + tq_aoi_kernel (A/B timing)
+static bool tq_rows_layout(const tq_cosmos_args& a) {
+  static const bool enabled = [] {
+    const char* e = getenv("TAPQIR_AMD_ROWS");
+    return !(e && e[0] == '0');
+  }();
+  return enabled && a.fuse_adam && !a.ndx && !a.fdx && a.nb == a.Nt && a.fb == a.F;
+}
+TQ_HD int tq_rows_nchunk(const tq_cosmos_args& a) { return (int)(((int64_t)a.F * a.C + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK); }
+
+template <int K>
+__global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_cosmos_args a, const int nchunk) {
+  __shared__ float s_part[TQ_UNIT_BLOCK / 64][TQ_ROWS_MAXCOL];
+  const int n = (int)blockIdx.y;
+  const int FC = a.F * a.C;
+  const int within = (int)blockIdx.x * TQ_UNIT_BLOCK + (int)threadIdx.x;
+  const bool live = within < FC;
+  const int64_t i = (int64_t)n * FC + within;
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_AOICOL + nq;
+  float part[TQ_MAX_NGSUM], aoi[TQ_ROWS_AOICOL];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < TQ_ROWS_AOICOL; ++j) aoi[j] = 0.0f;
+  if (live) {
+    float aoi2[2];
+    tq_body_unit<K>(a, i, part, aoi2);
+    const int c = within % a.C;
+#pragma unroll
+    for (int q = 0; q < TQ_MAXQ; ++q) {
+      aoi[2 * q] = (q == c) ? aoi2[0] : 0.0f;
+      aoi[2 * q + 1] = (q == c) ? aoi2[1] : 0.0f;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < TQ_ROWS_AOICOL; ++j) {
+    if (j < 2 * a.C) {
+      const float sum = tq_wave_sum(aoi[j]);
+      if (lane == 0) s_part[wave][j] = sum;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const float sum = tq_wave_sum(part[j]);
+      if (lane == 0) s_part[wave][TQ_ROWS_AOICOL + j] = sum;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ncol) {
+    const bool used = (int)threadIdx.x >= TQ_ROWS_AOICOL || (int)threadIdx.x < 2 * a.C;
+    const float sum = used ? (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]) : 0.0f;
+    a.blk_part[((int64_t)n * nchunk + blockIdx.x) * ncol + threadIdx.x] = sum;
+  }
+}
+
+// Tail of a step whose per-unit kernel wrote AOI-aligned rows (ONE workgroup of 256 threads): per-AOI sites from the
+// AOI's rows, cross-unit sums in fp64, global sites and the total ELBO.
+__device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_AOICOL + nq, nchunk = tq_rows_nchunk(a);
+  const int64_t nrows = (int64_t)a.Nt * nchunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[TQ_MAX_NGSUM];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
+  // per-AOI sites: frame sums = sums over the AOI's workgroup rows; prior terms; gradient of the AOI parameters
+  const int nac = a.Nt * a.C;
+  for (int ac = threadIdx.x; ac < nac; ac += 256) {
+    const int ai = ac / a.C, c = ac - ai * a.C;
+    float s1 = 0.0f, s2 = 0.0f;
+    const float* row = a.blk_part + (int64_t)ai * nchunk * ncol + 2 * c;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      s1 += row[(int64_t)ch * ncol];
+      s2 += row[(int64_t)ch * ncol + 1];
+    }
+    float e;
+    tq_body_aoi_finish(a, ai, c, s1, s2, &e);
+    acc[TQ_GS_ELBO] += (double)e;
+  }
+  for (int64_t r = threadIdx.x; r < nrows; r += 256) {
+#pragma unroll
+    for (int j = 0; j < TQ_MAX_NGSUM; ++j)
+      if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_AOICOL + j];
+  }
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const double s = tq_wave_sum_d(acc[j]);
+      if (lane == 0) s_w[wave][j] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+  __threadfence_block();
+  __syncthreads();
+  tq_globals_from_gsum_body(a, s_e);
+}
+
+__global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_cosmos_args a) {
+  __shared__ double s_w[4][TQ_MAX_NGSUM];
+  __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+  tq_rows_reduce_globals_body(a, s_w, s_e);
+}
+
 // Full-batch pipeline (tq_cosmos_step_overlapped): the local guide sampling of step t, with ONE extra workgroup (block (0, 0),
 // dispatched first) that runs the single-workgroup tail of step t-1 -- cross-unit sums, global sites, total ELBO, Adam
 // of the per-AOI / global parameters -- and then draws the global sites of step t from the updated parameters.  The
@@ -215,15 +335,16 @@ __global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_ar
 // step t-1), so the ~35 us latency chain of the tail hides behind the ~14 000 sampling workgroups of the same launch.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tq_sample_locals_tail_kernel(
     const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B, const int site_begin) {
-  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first), 2 = gsum of `prev` is complete
-  // (all-reduced by the caller): global sites onwards
+  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 = the same from AOI-aligned
+  // rows, per-AOI sites included), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
   if (blockIdx.y == 0) {
     if (blockIdx.x != 0) return;
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
-      if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
+      if (has_prev == 3) tq_rows_reduce_globals_body(prev, s_w, s_e);
+      else if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
       else tq_globals_from_gsum_body(prev, s_e);
       __syncthreads();
       const int64_t total = tq_num_params(prev);
@@ -239,6 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y - 1, i);
 }
+
 
 // ---------------------------------------------------------------------------------------------------------
 static int check_launch(const char* what) {
@@ -302,17 +424,10 @@ extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
   return check_launch("tq_sample_locals_kernel");
 }
 
-static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_sums) {
-  if (int rc = check_args(a, "elbo_grads")) return rc;
-  if (!a->images || !a->xy || !a->is_ontarget || !a->offset_samples || !a->offset_logits || !a->grad || !a->lat ||
-      !a->site || !a->pix || !a->aoi_part || !a->blk_part || !a->gsum) {
-    tq_set_error("tq_cosmos_elbo_grads: NULL required pointer");
-    return TQ_ERR_ARG;
-  }
-  hipStream_t st = (hipStream_t)stream;
+// pixel kernel of a step: fused render + log-likelihood + pathwise gradients, Dice weights from m_probs
+static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   const int K = a->K, M = 1 << K;
   const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
-  // 1. pixel kernel: fused render + log-likelihood + pathwise gradients, Dice weights from m_probs
   tq_ksmogn_args k = {};
   k.images = a->images; k.images_il = a->images_il; k.xy = a->xy; k.ndx = a->ndx; k.fdx = a->fdx;
   k.nb_full = a->Nt;
@@ -358,11 +473,37 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
     x.g_height = k.g_height; x.g_width = k.g_width; x.g_x = k.g_x; x.g_y = k.g_y;
     x.nb = a->nb; x.fb = a->fb; x.C = a->C; x.F = a->F; x.P = a->P; x.K = K; x.O = a->O;
     x.scale = a->scale;
-    if (int rc = tq_ksmogn_crosstalk_log_prob(&x, stream)) return rc;
-  } else if (int rc = tq_ksmogn_log_prob(&k, stream)) {
-    return rc;
+    return tq_ksmogn_crosstalk_log_prob(&x, stream);
   }
+  return tq_ksmogn_log_prob(&k, stream);
+}
+
+// rows: AOI-aligned per-unit kernel whose tail also finishes the per-AOI sites (tq_unit_rows_kernel; full-batch steps
+// that finish with tq_cosmos_tail or inside the next tq_cosmos_step_overlapped)
+static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_sums, bool rows = false) {
+  if (int rc = check_args(a, "elbo_grads")) return rc;
+  if (!a->images || !a->xy || !a->is_ontarget || !a->offset_samples || !a->offset_logits || !a->grad || !a->lat ||
+      !a->site || !a->pix || (!rows && !a->aoi_part) || !a->blk_part || !a->gsum) {
+    tq_set_error("tq_cosmos_elbo_grads: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int K = a->K;
+  const int64_t B = tq_batch_units(*a);
+  // 1. pixel kernel
+  if (int rc = launch_likelihood(a, stream)) return rc;
   // 2. per-unit sites
+  if (rows) {
+    const int nchunk = tq_rows_nchunk(*a);
+    const dim3 grid((unsigned)nchunk, (unsigned)a->Nt), block(TQ_UNIT_BLOCK);
+    switch (K) {
+      case 1: hipLaunchKernelGGL((tq_unit_rows_kernel<1>), grid, block, 0, st, *a, nchunk); break;
+      case 2: hipLaunchKernelGGL((tq_unit_rows_kernel<2>), grid, block, 0, st, *a, nchunk); break;
+      case 3: hipLaunchKernelGGL((tq_unit_rows_kernel<3>), grid, block, 0, st, *a, nchunk); break;
+      default: hipLaunchKernelGGL((tq_unit_rows_kernel<4>), grid, block, 0, st, *a, nchunk); break;
+    }
+    return check_launch("tq_unit_rows_kernel");
+  }
   const int64_t nblk = tq_cosmos_nblk(B);
   const dim3 grid((unsigned)nblk), block(TQ_UNIT_BLOCK);
   switch (K) {
@@ -431,7 +572,11 @@ static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
     tq_set_error("tq_cosmos_step: NULL required pointer");
     return TQ_ERR_ARG;
   }
-  // no all-reduce on this path: sums, global sites and the total ELBO finish in one launch
+  // no all-reduce on this path: sums, (per-AOI sites,) global sites and the total ELBO finish in one launch
+  if (tq_rows_layout(*a)) {
+    hipLaunchKernelGGL(tq_rows_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a);
+    return check_launch("tq_rows_reduce_globals_kernel");
+  }
   const int64_t B = tq_batch_units(*a);
   hipLaunchKernelGGL(tq_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a, tq_cosmos_nblk(B), B);
   return check_launch("tq_reduce_globals_kernel");
@@ -464,7 +609,7 @@ extern "C" int tq_cosmos_step(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "step")) return rc;
   if (int rc = tq_cosmos_sample_globals(a, stream)) return rc;
   if (int rc = tq_cosmos_sample_locals(a, stream)) return rc;
-  if (int rc = elbo_grads_impl(a, stream, false)) return rc;
+  if (int rc = elbo_grads_impl(a, stream, false, tq_rows_layout(*a))) return rc;
   return tq_cosmos_tail(a, stream);
 }
 
@@ -478,15 +623,23 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
   }
   if (!a->lat || !a->site || !a->grad || !a->gsum || !a->elbo_out || !a->exp_avg || !a->exp_avg_sq ||
       (prev && (!prev->grad || !prev->gsum || !prev->elbo_out || !prev->exp_avg || !prev->exp_avg_sq || !prev->blk_part ||
-                !prev->aoi_part))) {
+                (!tq_rows_layout(*prev) && !prev->aoi_part)))) {
     tq_set_error("tq_cosmos_step_overlapped: NULL required pointer");
     return TQ_ERR_ARG;
   }
   const int64_t B = tq_batch_units(*a);
   hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(2 + 4 * a->K)), dim3(256), 0,
-                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? 1 : 0, B, 0);
+                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? (tq_rows_layout(*prev) ? 3 : 1) : 0, B, 0);
   if (int rc = check_launch("tq_sample_locals_tail_kernel")) return rc;
-  return elbo_grads_impl(a, stream, false);
+  return elbo_grads_impl(a, stream, false, tq_rows_layout(*a));
+}
+
+
+extern "C" int64_t tq_cosmos_blk_floats(int32_t Nt, int32_t F, int32_t C, int32_t crosstalk, int64_t B) {
+  const int64_t nchunk = ((int64_t)F * C + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK;
+  const int64_t rows = (int64_t)Nt * nchunk * (TQ_ROWS_AOICOL + TQ_NGSUM_X(C, crosstalk));
+  const int64_t flat = tq_cosmos_nblk(B) * TQ_NGSUM_X(C, crosstalk);
+  return rows > flat ? rows : flat;
 }
 
 // AOI-sharded pipeline: the local sites [site_begin, site_begin + site_count) of `a`; with `prev` (whose gsum the caller

@@ -143,6 +143,9 @@ class CosmosEngine:
         _lib.check(self.lib.tq_image_stats(_lib.ptr(self.images), _lib.ptr(self.offset_samples), _lib.ptr(self.pixstats),
                                            U, self.P, self._stream()), "tq_image_stats")
 
+    def _blk_floats(self, B):
+        return int(self.lib.tq_cosmos_blk_floats(self.Nt, self.F, self.C, int(self.crosstalk), B))
+
     def run_probs(self, a):
         _lib.check(self.lib.tq_cosmos_probs(C.byref(a), self._stream()), "tq_cosmos_probs")
 
@@ -203,7 +206,7 @@ class CosmosEngine:
         self.pix = torch.zeros((M + 2 + 4 * K + (1 + self.C if self.crosstalk else 0)) * B, dtype=f32, device=dev)
         self.aoi_part = torch.zeros(3 * B, dtype=f32, device=dev)
         nblk = (B + 255) // 256
-        self.blk_part = torch.zeros(nblk * self.n_gsum, dtype=f32, device=dev)
+        self.blk_part = torch.zeros(self._blk_floats(B), dtype=f32, device=dev)
         self._ws_key = key
 
     def _index_to_device(self, idx, which):

@@ -82,6 +82,9 @@ class HostCheckEngine(HipEngine):
     def _stream(self):
         return None
 
+    def _blk_floats(self, B):
+        return ((B + 255) // 256) * self.n_gsum
+
     def call(self, name, args):
         getattr(self.lib, "hc_" + name)(C.byref(args))
 
