@@ -21,6 +21,7 @@
 // vs the quarter-rate transcendental pipe -- see DESIGN.md.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/tapqir_hip.h"
@@ -818,6 +819,271 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
 }
 
 // =============================================================================================
+// Persistent form of the packed kernel (backward pass of full-batch steps).
+//
+// tq_ksmogn_il2_kernel spends ~7 us per round of its one-wave workgroups outside the pixel loop: a fresh wave waits for
+// its unit parameters (one HBM round trip), computes the x-factor table, runs the loop, then waits again for the data
+// statistics before it can store -- and with two waves per SIMD only the sibling wave can cover that.  Here a wave
+// stays resident and walks over tiles (tile = 64 units): while it runs the LAST loop body of a tile, the next tile's
+// per-unit scalars (target position, draws, m_probs logits, data statistics: 6 + 5K dwords per unit) stream into a
+// wave-private LDS slab by LDS-DMA (global_load_lds_dword: no VGPRs, nothing to spill at 216 registers) and the image
+// ring is refilled with the next tile's first groups, so a tile starts from LDS reads and registers that are already
+// full.  Two slabs alternate: the epilogue of tile t still reads slab t (spot heights / widths, statistics).
+// The compiler does not order LDS reads behind LDS-DMA writes: the explicit vmcnt(0) at the top of a tile does.
+// =============================================================================================
+#define TQ_P_NPAR(K) (6 + 5 * (K))
+#ifndef TQ_P_DMA_EARLY
+#define TQ_P_DMA_EARLY 1
+#endif
+
+template <int K, int P, bool BWD>
+__global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(const tq_ksmogn_args a, const int64_t B,
+                                                                              const int ntiles) {
+  static_assert(P % 2 == 0 && (P * P) % 4 == 0, "packed kernel needs an even tile side");
+  constexpr int M = 1 << K;
+  constexpr int R = ((P / 2) % 2) ? 2 : 1;
+  constexpr int G = R * P / 4;
+  constexpr int NB = P / R;
+  constexpr int npix = P * P, npix4 = npix / 4;
+  constexpr bool COLACC = BWD && (K * P <= 28);
+  constexpr int NPAR = TQ_P_NPAR(K);
+  // slab rows: 0 tx, 1 ty, 2 b, 3.. h[K], w[K], x[K], y[K], m_logit[K], then the 3 data statistics
+  constexpr int R_H = 3, R_W = 3 + K, R_X = 3 + 2 * K, R_Y = 3 + 3 * K, R_M = 3 + 4 * K, R_S = 3 + 5 * K;
+  __shared__ float s_par[2][NPAR][64];
+  const int lane = threadIdx.x;
+  const float4* il = reinterpret_cast<const float4*>(a.images_il);
+
+  const float g = a.gain[0];
+  const float rg = TQ_FRCP(g);
+  const float ln_g = TQ_FLOG(g);
+  const float off0 = a.offset_samples[0];
+  TqFastConst c;
+  {
+    const float g2 = g * g, rl2 = 1.0f / TQ_LN2;
+    c.ca = TQ_LN2 * rg;
+    c.cb = 0.5f * TQ_LN2;
+    c.s1 = g * (1.0f / 12.0f);
+    c.s3 = -g2 * g * (1.0f / 360.0f);
+    c.d1 = 0.5f * g * rl2;
+    c.d2 = g2 * (1.0f / 12.0f) * rl2;
+    c.d4 = -g2 * g2 * (1.0f / 120.0f) * rl2;
+  }
+  const float sc_plate = a.scale;
+
+  // per-unit scalars of tile `t` -> slab `buf` (LDS-DMA; lanes beyond B shadow the last unit)
+  auto prefetch_params = [&](const int t, const int buf) {
+    // wave-uniform row base (scalar registers) + one 32-bit lane offset: the 6 + 5K requests share a single address VGPR
+    const int64_t t0 = (int64_t)t * 64;
+    const int64_t rem = B - 1 - t0;  // >= 0: t < ntiles
+    const uint32_t l = (uint32_t)lane < (uint32_t)rem ? (uint32_t)lane : (uint32_t)rem;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    auto put = [&](const float* row_base, const uint32_t off, const int row) {
+      __builtin_amdgcn_global_load_lds((gptr)(row_base + off), (lptr)&s_par[buf][row][0], 4, 0, 0);
+    };
+    put(a.xy + 2 * t0, 2 * l, 0);
+    put(a.xy + 2 * t0 + 1, 2 * l, 1);
+    put(a.background + t0, l, 2);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      put(a.height + k * B + t0, l, R_H + k);
+      put(a.width + k * B + t0, l, R_W + k);
+      put(a.x + k * B + t0, l, R_X + k);
+      put(a.y + k * B + t0, l, R_Y + k);
+      put(a.m_logit + k * a.m_kstride + t0, l, R_M + k);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) put(a.pixstats + j * a.stats_stride + t0, l, R_S + j);
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  prefetch_params(t, 0);
+  float4 ring[G];
+  {
+    const float4* src0 = il + ((int64_t)t * npix4) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < G; ++j) ring[j] = src0[j * 64];
+  }
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+    const int tn = t + (int)gridDim.x;
+    const bool has_next = tn < ntiles;
+    const int64_t i_raw = (int64_t)t * 64 + lane;
+    const bool live = i_raw < B;
+    const int64_t i = live ? i_raw : (B - 1);
+    const float4* src = il + ((int64_t)t * npix4) * 64 + lane;
+    const float4* src_next = il + ((int64_t)(has_next ? tn : t) * npix4) * 64 + lane;
+    // the slab of this tile was requested one loop body ago (or before the loop)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float (*sp)[64] = s_par[buf];
+    const float tx = sp[0][lane], ty = sp[1][lane];
+    const float b = sp[2][lane];
+    float amph[K], nl2[K], cx[K], cy[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float hk = sp[R_H + k][lane], wk = sp[R_W + k][lane];
+      cx[k] = sp[R_X + k][lane] + tx;
+      cy[k] = sp[R_Y + k][lane] + ty;
+      const float inv2v = 0.5f * TQ_FRCP(wk * wk);
+      amph[k] = hk * inv2v * (1.0f / TQ_PI);
+      nl2[k] = -inv2v * 1.44269504088896340736f;
+    }
+    float W[M];
+#pragma unroll
+    for (int mi = 0; mi < M; ++mi) W[mi] = 0.0f;
+    if (BWD) {
+      float p1[K], p0[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float uk = sp[R_M + k][lane];
+        p1[k] = tq_fast_sigmoid(uk);
+        p0[k] = tq_fast_sigmoid(-uk);
+      }
+      const int n = (int)((uint32_t)i / (uint32_t)(a.F * a.C));
+      const float sc = sc_plate * ((a.aoi_mask == nullptr || a.aoi_mask[n]) ? 1.0f : 0.0f);
+#pragma unroll
+      for (int mi = 0; mi < M; ++mi) {
+        float w = sc;
+#pragma unroll
+        for (int k = 0; k < K; ++k) w *= ((mi >> k) & 1) ? p1[k] : p0[k];
+        W[mi] = w;
+      }
+    }
+
+    TqPixAcc<K> S;
+    tq_acc_zero<K>(S);
+    const bool fastpath = __all(b * rg >= TQ_FAST_ALPHA);
+    if (fastpath) {
+      tq_f2 ex[K][P / 2];
+      float sum_ex[K], sum_gy[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        tq_f2 acc = tq2(0.0f);
+#pragma unroll
+        for (int ip = 0; ip < P / 2; ++ip) {
+          const tq_f2 dx = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)} - cx[k];
+          ex[k][ip] = tq2_exp2(dx * dx * nl2[k]);
+          acc += ex[k][ip];
+        }
+        sum_ex[k] = acc.x + acc.y;
+        sum_gy[k] = 0.0f;
+      }
+      TqPixAcc2<K, P, COLACC> A;
+#pragma unroll
+      for (int mi = 0; mi < M; ++mi) A.T[mi] = tq2(0.0f);
+      A.acc_b = tq2(0.0f);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        A.S0r[k] = A.S0[k] = A.Sy[k] = A.Syy[k] = A.Sx[k] = A.Sxx[k] = tq2(0.0f);
+        if (COLACC) {
+#pragma unroll
+          for (int ip = 0; ip < P / 2; ++ip) A.col[k][ip] = tq2(0.0f);
+        }
+      }
+      // one loop body = R rows; the groups of the following body (of the next tile's first body in the last one) are
+      // fetched as those of this one retire.  TQ_P_DMA_EARLY: the next tile's scalars are requested at the top of the last
+      // body (a whole body of cover) instead of after it (cover = the epilogue)
+#pragma unroll 1
+      for (int body = 0; body < NB; ++body) {
+        const bool last = body == NB - 1;
+#if TQ_P_DMA_EARLY
+        if (last && has_next) prefetch_params(tn, buf ^ 1);
+#endif
+        const float4* nxt = last ? src_next : src + (int64_t)(body + 1) * G * 64;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          const float fj = (float)(body * R + rr);
+          float agy[K], dyk[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            dyk[k] = fj - cy[k];
+            agy[k] = amph[k] * __builtin_amdgcn_exp2f(dyk[k] * dyk[k] * nl2[k]);
+            sum_gy[k] += agy[k];
+          }
+#pragma unroll
+          for (int ip = 0; ip < P / 2; ++ip) {
+            const int pair = rr * (P / 2) + ip;
+            const int gi = pair >> 1;
+            const float4 d4 = ring[gi];
+            const tq_f2 v = ((pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y}) - off0;
+            if (pair & 1) {  // last use of the group: refill it in place with the same group of the next body / tile
+              __builtin_amdgcn_sched_barrier(0);
+              ring[gi] = nxt[gi * 64];
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            tq_f2 spot[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) spot[k] = agy[k] * ex[k][ip];
+            tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c);
+          }
+          if (BWD) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              if (!COLACC) A.S0[k] += A.S0r[k];
+              A.Sy[k] += A.S0r[k] * dyk[k];
+              A.Syy[k] += A.S0r[k] * (dyk[k] * dyk[k]);
+            }
+          }
+        }
+      }
+#if !TQ_P_DMA_EARLY
+      if (has_next) prefetch_params(tn, buf ^ 1);
+#endif
+#pragma unroll
+      for (int mi = 1; mi < M; ++mi) S.sS[mi] = -(A.T[mi].x + A.T[mi].y);
+#pragma unroll
+      for (int k = 0; k < K; ++k) S.SN[k] = sum_ex[k] * sum_gy[k];
+      if (BWD) {
+        S.acc_b = (A.acc_b.x + A.acc_b.y) * TQ_LN2;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          tq_f2 s0 = A.S0[k], sx = A.Sx[k], sxx = A.Sxx[k];
+          if (COLACC) {
+            s0 = sx = sxx = tq2(0.0f);
+            float cxe = cx[k];
+            asm volatile("" : "+v"(cxe));
+#pragma unroll
+            for (int ip = 0; ip < P / 2; ++ip) {
+              const tq_f2 dxc = (tq_f2){(float)(2 * ip), (float)(2 * ip + 1)} - cxe;
+              s0 += A.col[k][ip];
+              sx += A.col[k][ip] * dxc;
+              sxx += A.col[k][ip] * (dxc * dxc);
+            }
+          }
+          S.S0[k] = (s0.x + s0.y) * TQ_LN2;
+          S.Sx[k] = (sx.x + sx.y) * TQ_LN2;
+          S.Sy[k] = (A.Sy[k].x + A.Sy[k].y) * TQ_LN2;
+          S.Sr[k] = (sxx.x + sxx.y + A.Syy[k].x + A.Syy[k].y) * TQ_LN2;
+        }
+      }
+    } else {
+      // some unit of this tile has a small alpha = background / gain: general (scalar, exact Binet) loop on the tile in
+      // memory; the ring keeps the groups of body 0 and must be re-aimed at the next tile before it is used again
+      tq_il_pixel_loop<K, true, BWD, false>(S, a, src, P, npix, b, amph, nl2, cx, cy, g, rg, ln_g, W);
+      if (has_next) prefetch_params(tn, buf ^ 1);
+#pragma unroll
+      for (int j = 0; j < G; ++j) ring[j] = src_next[j * 64];
+    }
+    const float S_v = sp[R_S][lane];
+    const float S_lv = sp[R_S + 1][lane];
+    const bool bad = sp[R_S + 2][lane] > 0.0f;
+    tq_pixel_assemble_one_offset<K, BWD>(a, S, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
+    if (live) {
+      float hk[K], wk[K], cxs[K], cys[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        hk[k] = sp[R_H + k][lane];
+        wk[k] = sp[R_W + k][lane];
+        cxs[k] = fastpath ? (COLACC ? 0.0f : cx[k] - 0.5f * (float)(P - 1)) : cx[k] - 0.5f * (float)(P - 1);
+        cys[k] = fastpath ? 0.0f : cy[k] - 0.5f * (float)(P - 1);
+      }
+      tq_pixel_store<K, true, BWD>(a, B, i, S, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
+    }
+  }
+}
+
+// =============================================================================================
 // Packed lane-per-unit kernel for an offset HISTOGRAM (O > 1; real data, glimpse_reader.py:414-421).
 // Same mapping as above (one lane per unit, two horizontally adjacent pixels per lane in float2
 // registers); per pixel pair the loop over the offset samples runs the formulation of tq_pixel.h:
@@ -1131,6 +1397,20 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     if (ONE && (a.P == 14 || a.P == 20)) {
       const dim3 grid1((unsigned)((B + 63) / 64)), block1(64);
+      static const int persist = [] {
+        const char* e = getenv("TAPQIR_AMD_PERSIST");
+        return e ? atoi(e) : 2;  // resident waves per SIMD that walk over the tiles; 0 = one wave per tile
+      }();
+      if (bwd && !a.gout && persist > 0 && K <= 2) {  // (K = 3 spills in this form)
+        const int ntiles = (int)((B + 63) / 64);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const int waves = cus * 4 * persist;
+        const dim3 gridp((unsigned)(ntiles < waves ? ntiles : waves));
+        if (a.P == 14) hipLaunchKernelGGL((tq_ksmogn_il2p_kernel<K, 14, true>), gridp, block1, 0, st, a, B, ntiles);
+        else hipLaunchKernelGGL((tq_ksmogn_il2p_kernel<K, 20, true>), gridp, block1, 0, st, a, B, ntiles);
+        return launch_status("tq_ksmogn_il2p_kernel");
+      }
       if (a.P == 14) {
         if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, true>), grid1, block1, 0, st, a, B);
         else hipLaunchKernelGGL((tq_ksmogn_il2_kernel<K, 14, false>), grid1, block1, 0, st, a, B);
