@@ -204,8 +204,8 @@ typedef struct {
   float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */
   float* blk_part;             /* tq_cosmos_blk_floats() floats: per-workgroup partial sums, [nblk][3+3Q] (crosstalk:
                                                    3+3Q+Q*Q), or -- full-batch steps run by tq_cosmos_step /
-                                                   tq_cosmos_step_overlapped, whose workgroups are AOI-aligned --
-                                                   [Nt][chunks][8 + 3+3Q(+Q*Q)] with the per-AOI frame sums in front */
+                                                   tq_cosmos_step_overlapped -- [nblk][16 + 3+3Q(+Q*Q)] with the
+                                                   per-AOI frame sums of the (at most two) AOIs a workgroup touches in front */
   double* gsum;                /* [TQ_GSUM_LEN]    cross-unit sums: d/d gain, d/d cs, ELBO, (d/d rho, a, c)[Q] in the
                                                    first 3+3Q entries (the part a data-parallel host
                                                    all-reduces); the tail is scratch of the library */

@@ -211,56 +211,63 @@ __global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_ar
 }
 
 // =============================================================================================================
-// AOI-aligned per-unit kernel of full-batch steps (tq_cosmos_step_overlapped / tq_cosmos_step).
+// Per-unit kernel of full-batch steps (tq_cosmos_step_overlapped / tq_cosmos_step) with the per-AOI frame sums folded in.
 //
-// Grid: x = chunks of 256 units within one AOI (the units (f, c) of AOI n are contiguous), y = AOI.  A workgroup
-// therefore belongs to ONE AOI and its row of partial sums can carry, next to the cross-unit sums, the frame sums of
-// d/d(background_mean_loc, background_std_loc) of that AOI: the single-workgroup tail adds the few rows of an AOI
-// itself, so there is no per-AOI kernel (5 us + a launch boundary at 400 000 units) and no aoi_part round trip
-// (16 B per unit).  Row layout: [2 * TQ_MAXQ per-channel AOI partials][nq cross-unit sums]; the fixed offset keeps
-// every register-array index a compile-time constant.
+// The units (f, c) of an AOI are contiguous, so a workgroup of 256 consecutive units touches at most TWO AOIs (when
+// F * C >= 256): its row of partial sums carries, next to the cross-unit sums, the sums of
+// d/d(background_mean_loc, background_std_loc) over its units of the first AOI (slot 0) and of the second (slot 1).  The
+// single-workgroup tail adds the few rows that overlap an AOI itself, so there is no per-AOI kernel (5 us + a launch
+// boundary at 400 000 units) and no aoi_part round trip (16 B per unit).  Workgroups stay 1 KiB-aligned in every
+// parameter row (AOI-aligned workgroups start at n * F * C and straddle cache lines: 9 % slower, measured).
+// Row layout: [2 slots][2 * TQ_MAXQ per-channel AOI partials][nq cross-unit sums]; fixed offsets keep every
+// register-array index a compile-time constant.
 // =============================================================================================================
 #define TQ_ROWS_AOICOL (2 * TQ_MAXQ)
-#define TQ_ROWS_MAXCOL (TQ_ROWS_AOICOL + TQ_MAX_NGSUM)
+#define TQ_ROWS_GCOL (2 * TQ_ROWS_AOICOL)
+#define TQ_ROWS_MAXCOL (TQ_ROWS_GCOL + TQ_MAX_NGSUM)
 
-// (host) does this step use the AOI-aligned layout?  TAPQIR_AMD_ROWS=0 keeps the flat layout + tq_aoi_kernel (A/B timing)
+// (host) does this step use the rows layout?  TAPQIR_AMD_ROWS=0 keeps the flat layout + tq_aoi_kernel (A/B timing)
 static bool tq_rows_layout(const tq_cosmos_args& a) {
   static const bool enabled = [] {
     const char* e = getenv("TAPQIR_AMD_ROWS");
     return !(e && e[0] == '0');
   }();
-  return enabled && a.fuse_adam && !a.ndx && !a.fdx && a.nb == a.Nt && a.fb == a.F;
+  return enabled && a.fuse_adam && !a.ndx && !a.fdx && a.nb == a.Nt && a.fb == a.F && a.F * a.C >= TQ_UNIT_BLOCK;
 }
-TQ_HD int tq_rows_nchunk(const tq_cosmos_args& a) { return (int)(((int64_t)a.F * a.C + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK); }
 
 template <int K>
-__global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_cosmos_args a, const int nchunk) {
+__global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_cosmos_args a, const int64_t B) {
   __shared__ float s_part[TQ_UNIT_BLOCK / 64][TQ_ROWS_MAXCOL];
-  const int n = (int)blockIdx.y;
-  const int FC = a.F * a.C;
-  const int within = (int)blockIdx.x * TQ_UNIT_BLOCK + (int)threadIdx.x;
-  const bool live = within < FC;
-  const int64_t i = (int64_t)n * FC + within;
-  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_AOICOL + nq;
-  float part[TQ_MAX_NGSUM], aoi[TQ_ROWS_AOICOL];
+  const int64_t i = (int64_t)blockIdx.x * TQ_UNIT_BLOCK + threadIdx.x;
+  const bool live = i < B;
+  const uint32_t FC = (uint32_t)(a.F * a.C);
+  const uint32_t n0 = ((uint32_t)blockIdx.x * TQ_UNIT_BLOCK) / FC;  // AOI of the workgroup's first unit
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  float part[TQ_MAX_NGSUM], aoi[TQ_ROWS_GCOL];
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
 #pragma unroll
-  for (int j = 0; j < TQ_ROWS_AOICOL; ++j) aoi[j] = 0.0f;
+  for (int j = 0; j < TQ_ROWS_GCOL; ++j) aoi[j] = 0.0f;
   if (live) {
     float aoi2[2];
     tq_body_unit<K>(a, i, part, aoi2);
-    const int c = within % a.C;
+    const uint32_t n = (uint32_t)i / FC;
+    const int c = (int)((uint32_t)i % (uint32_t)a.C);
+    const int slot = n == n0 ? 0 : 1;
 #pragma unroll
-    for (int q = 0; q < TQ_MAXQ; ++q) {
-      aoi[2 * q] = (q == c) ? aoi2[0] : 0.0f;
-      aoi[2 * q + 1] = (q == c) ? aoi2[1] : 0.0f;
+    for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+      for (int q = 0; q < TQ_MAXQ; ++q) {
+        const bool mine = sl == slot && q == c;
+        aoi[sl * TQ_ROWS_AOICOL + 2 * q] = mine ? aoi2[0] : 0.0f;
+        aoi[sl * TQ_ROWS_AOICOL + 2 * q + 1] = mine ? aoi2[1] : 0.0f;
+      }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j < TQ_ROWS_AOICOL; ++j) {
-    if (j < 2 * a.C) {
+  for (int j = 0; j < TQ_ROWS_GCOL; ++j) {
+    if ((j % TQ_ROWS_AOICOL) < 2 * a.C) {
       const float sum = tq_wave_sum(aoi[j]);
       if (lane == 0) s_part[wave][j] = sum;
     }
@@ -269,44 +276,49 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
     if (j < nq) {
       const float sum = tq_wave_sum(part[j]);
-      if (lane == 0) s_part[wave][TQ_ROWS_AOICOL + j] = sum;
+      if (lane == 0) s_part[wave][TQ_ROWS_GCOL + j] = sum;
     }
   }
   __syncthreads();
   if ((int)threadIdx.x < ncol) {
-    const bool used = (int)threadIdx.x >= TQ_ROWS_AOICOL || (int)threadIdx.x < 2 * a.C;
+    const bool used = (int)threadIdx.x >= TQ_ROWS_GCOL || ((int)threadIdx.x % TQ_ROWS_AOICOL) < 2 * a.C;
     const float sum = used ? (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]) : 0.0f;
-    a.blk_part[((int64_t)n * nchunk + blockIdx.x) * ncol + threadIdx.x] = sum;
+    a.blk_part[(int64_t)blockIdx.x * ncol + threadIdx.x] = sum;
   }
 }
 
-// Tail of a step whose per-unit kernel wrote AOI-aligned rows (ONE workgroup of 256 threads): per-AOI sites from the
-// AOI's rows, cross-unit sums in fp64, global sites and the total ELBO.
+// Tail of a step whose per-unit kernel wrote such rows (ONE workgroup of 256 threads): per-AOI sites from the rows that
+// overlap the AOI, cross-unit sums in fp64, global sites and the total ELBO.
 __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
-  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_AOICOL + nq, nchunk = tq_rows_nchunk(a);
-  const int64_t nrows = (int64_t)a.Nt * nchunk;
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  const int64_t B = tq_batch_units(a);
+  const int64_t nrows = (B + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK;
+  const uint32_t FC = (uint32_t)(a.F * a.C);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc[TQ_MAX_NGSUM];
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
-  // per-AOI sites: frame sums = sums over the AOI's workgroup rows; prior terms; gradient of the AOI parameters
+  // per-AOI sites: frame sums = sums over the rows that overlap the AOI; prior terms; gradient of the AOI parameters
   const int nac = a.Nt * a.C;
   for (int ac = threadIdx.x; ac < nac; ac += 256) {
-    const int ai = ac / a.C, c = ac - ai * a.C;
+    const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;
+    const int c = ac - (int)ai * a.C;
+    const uint32_t r_lo = (ai * FC) / TQ_UNIT_BLOCK, r_hi = ((ai + 1) * FC - 1) / TQ_UNIT_BLOCK;
     float s1 = 0.0f, s2 = 0.0f;
-    const float* row = a.blk_part + (int64_t)ai * nchunk * ncol + 2 * c;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      s1 += row[(int64_t)ch * ncol];
-      s2 += row[(int64_t)ch * ncol + 1];
+    for (uint32_t r = r_lo; r <= r_hi; ++r) {
+      const int slot = (r * TQ_UNIT_BLOCK) / FC == ai ? 0 : 1;
+      const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
+      s1 += row[0];
+      s2 += row[1];
     }
     float e;
-    tq_body_aoi_finish(a, ai, c, s1, s2, &e);
+    tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
     acc[TQ_GS_ELBO] += (double)e;
   }
   for (int64_t r = threadIdx.x; r < nrows; r += 256) {
 #pragma unroll
     for (int j = 0; j < TQ_MAX_NGSUM; ++j)
-      if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_AOICOL + j];
+      if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_GCOL + j];
   }
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
@@ -494,13 +506,12 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
   if (int rc = launch_likelihood(a, stream)) return rc;
   // 2. per-unit sites
   if (rows) {
-    const int nchunk = tq_rows_nchunk(*a);
-    const dim3 grid((unsigned)nchunk, (unsigned)a->Nt), block(TQ_UNIT_BLOCK);
+    const dim3 grid((unsigned)tq_cosmos_nblk(B)), block(TQ_UNIT_BLOCK);
     switch (K) {
-      case 1: hipLaunchKernelGGL((tq_unit_rows_kernel<1>), grid, block, 0, st, *a, nchunk); break;
-      case 2: hipLaunchKernelGGL((tq_unit_rows_kernel<2>), grid, block, 0, st, *a, nchunk); break;
-      case 3: hipLaunchKernelGGL((tq_unit_rows_kernel<3>), grid, block, 0, st, *a, nchunk); break;
-      default: hipLaunchKernelGGL((tq_unit_rows_kernel<4>), grid, block, 0, st, *a, nchunk); break;
+      case 1: hipLaunchKernelGGL((tq_unit_rows_kernel<1>), grid, block, 0, st, *a, B); break;
+      case 2: hipLaunchKernelGGL((tq_unit_rows_kernel<2>), grid, block, 0, st, *a, B); break;
+      case 3: hipLaunchKernelGGL((tq_unit_rows_kernel<3>), grid, block, 0, st, *a, B); break;
+      default: hipLaunchKernelGGL((tq_unit_rows_kernel<4>), grid, block, 0, st, *a, B); break;
     }
     return check_launch("tq_unit_rows_kernel");
   }
@@ -636,10 +647,9 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
 
 
 extern "C" int64_t tq_cosmos_blk_floats(int32_t Nt, int32_t F, int32_t C, int32_t crosstalk, int64_t B) {
-  const int64_t nchunk = ((int64_t)F * C + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK;
-  const int64_t rows = (int64_t)Nt * nchunk * (TQ_ROWS_AOICOL + TQ_NGSUM_X(C, crosstalk));
+  const int64_t full = tq_cosmos_nblk((int64_t)Nt * F * C) * (TQ_ROWS_GCOL + TQ_NGSUM_X(C, crosstalk));  // full-batch rows
   const int64_t flat = tq_cosmos_nblk(B) * TQ_NGSUM_X(C, crosstalk);
-  return rows > flat ? rows : flat;
+  return full > flat ? full : flat;
 }
 
 // AOI-sharded pipeline: the local sites [site_begin, site_begin + site_count) of `a`; with `prev` (whose gsum the caller
