@@ -326,6 +326,56 @@ typedef struct {
 int tq_cosmos_probs(const tq_probs_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * KSMOGN.rsample (tapqir/distributions/ksmogn.py:171-185), the sampler behind tapqir/utils/simulate.py:108-122:
+ *   out[i, j, ic] = max(Gamma(mu / g, 1 / g), tiny) + offset_samples[odx],  odx ~ Categorical(offset_logits) per pixel,
+ *   mu = background + sum_k height_k N(ic; x_k + tx, w_k) N(j; y_k + ty, w_k).
+ * `height` carries the presence indicators (m_k h_k) and, for the crosstalk image of channel c, the fractions alpha_qc
+ * (then K = Q K' spots per unit).  Draws are distributionally (not bitwise) those of torch: Philox4x32-10 +
+ * Marsaglia-Tsang, one stream per pixel keyed by (seed, unit, pixel).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* height;         /* [K][B] */
+  const float* width;          /* [K][B] */
+  const float* x;              /* [K][B] */
+  const float* y;              /* [K][B] */
+  const float* xy;             /* [B][2] target locations */
+  const float* background;     /* [B] */
+  const float* gain;           /* [1] */
+  const float* offset_samples; /* [O] */
+  const float* offset_logits;  /* [O] */
+  float* out;                  /* [B][P][P] */
+  int64_t B;
+  int32_t P, K, O;
+  uint64_t seed;
+} tq_rsample_args;
+
+int tq_ksmogn_rsample(const tq_rsample_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Post-fit statistics of every unit (n, f, c): signal-to-noise ratio of each spot and chi2 of the fitted image.
+ * Replaces snr_and_chi2 (tapqir/utils/stats.py:29-86) and the per-AOI host loop around it (stats.py:166-182):
+ *   N_k      = N(ic; x_k + tx, w_k) N(j; y_k + ty, w_k)      with the posterior MEANS of the spot parameters
+ *   snr[k]   = sum_ij (D - b - offset_mean) N_k / sqrt(offset_var + b gain)
+ *   chi2     = mean_ij (D - (b + sum_k h_k N_k) - offset_mean)^2 / (b + sum_k h_k N_k)
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* images;         /* (Nt, F, C, P, P) */
+  const float* xy;             /* (Nt, F, C, 2) */
+  const float* height;         /* [K][U] posterior means, U = Nt*F*C */
+  const float* width;          /* [K][U] */
+  const float* x;              /* [K][U] */
+  const float* y;              /* [K][U] */
+  const float* background;     /* [U] */
+  float* snr;                  /* [K][U] out */
+  float* chi2;                 /* [U] out */
+  int64_t U;
+  int32_t P, K;
+  float gain, offset_mean, offset_var;
+} tq_snr_args;
+
+int tq_snr_chi2(const tq_snr_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Input side: AOI extraction from raw Glimpse frames.
  * Replaces the per-frame / per-AOI loop of read_glimpse (tapqir/imscroll/glimpse_reader.py:358-392), the frame
  * decode of GlimpseDataset.__getitem__ (168-186: big-endian int16 + 2^15) and the offset-region value counts

@@ -97,6 +97,27 @@ class ProbsArgs(C.Structure):
     ]
 
 
+class RsampleArgs(C.Structure):
+    """``tq_rsample_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("height", C.c_void_p), ("width", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p), ("xy", C.c_void_p),
+        ("background", C.c_void_p), ("gain", C.c_void_p), ("offset_samples", C.c_void_p), ("offset_logits", C.c_void_p),
+        ("out", C.c_void_p), ("B", C.c_int64), ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+class SnrArgs(C.Structure):
+    """``tq_snr_args`` (include/tapqir_hip.h)."""
+
+    _fields_ = [
+        ("images", C.c_void_p), ("xy", C.c_void_p), ("height", C.c_void_p), ("width", C.c_void_p), ("x", C.c_void_p),
+        ("y", C.c_void_p), ("background", C.c_void_p), ("snr", C.c_void_p), ("chi2", C.c_void_p),
+        ("U", C.c_int64), ("P", C.c_int32), ("K", C.c_int32),
+        ("gain", C.c_float), ("offset_mean", C.c_float), ("offset_var", C.c_float),
+    ]
+
+
 class GlimpseArgs(C.Structure):
     """``tq_glimpse_args`` (include/tapqir_hip.h)."""
 
@@ -117,7 +138,7 @@ EXPORTS = [
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
     "tq_cosmos_blk_floats",
-    "tq_cosmos_probs", "tq_glimpse_extract",
+    "tq_cosmos_probs", "tq_glimpse_extract", "tq_ksmogn_rsample", "tq_snr_chi2",
 ]
 
 _lib = None
@@ -178,6 +199,10 @@ def load():
     lib.tq_cosmos_adam_catchup.restype = C.c_int
     lib.tq_cosmos_probs.argtypes = [C.POINTER(ProbsArgs), C.c_void_p]
     lib.tq_cosmos_probs.restype = C.c_int
+    lib.tq_ksmogn_rsample.argtypes = [C.POINTER(RsampleArgs), C.c_void_p]
+    lib.tq_ksmogn_rsample.restype = C.c_int
+    lib.tq_snr_chi2.argtypes = [C.POINTER(SnrArgs), C.c_void_p]
+    lib.tq_snr_chi2.restype = C.c_int
     lib.tq_glimpse_extract.argtypes = [C.POINTER(GlimpseArgs), C.c_void_p]
     lib.tq_glimpse_extract.restype = C.c_int
     _lib = lib

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtapqir_hip.so")
-SOURCES = ["tq_ksmogn.hip", "tq_xtalk.hip", "tq_cosmos.hip", "tq_glimpse.hip"]
+SOURCES = ["tq_ksmogn.hip", "tq_xtalk.hip", "tq_cosmos.hip", "tq_glimpse.hip", "tq_aux.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
 
 

@@ -18,7 +18,7 @@ shape (..., Q, K), ``background`` (..., C), ``target_locs`` (..., C, 2), the eve
 import ctypes as C
 
 import torch
-from torch.distributions import Categorical, constraints
+from torch.distributions import constraints
 from torch.distributions.distribution import Distribution
 
 from tapqir_amd import _lib
@@ -172,13 +172,51 @@ class KSMOGN(Distribution):
         g = gaussian_spots(self.height, self.width, self.x, self.y, self.target_locs.unsqueeze(-2), self.P, self.m)
         return self.background_[..., None, None] + g.sum(-3)
 
-    def rsample(self, sample_shape=torch.Size()):
-        """ksmogn.py:171-185."""
-        conc = self.image / self.gain
+    def rsample(self, sample_shape=torch.Size(), seed=None):
+        """ksmogn.py:171-185: per pixel ``Gamma(image / gain, 1 / gain) + offset_samples[odx]``,
+        ``odx ~ Categorical(offset_logits)``; drawn by ``tq_ksmogn_rsample`` (Philox + Marsaglia-Tsang on the device:
+        the law of torch's sampler, not its bit stream).  ``seed`` defaults to a draw from torch's global generator, so
+        ``torch.manual_seed`` makes simulations reproducible."""
+        dev = self.height.device
+        if dev.type != "cuda":
+            raise HipExtensionError("KSMOGN.rsample runs on the HIP device only (no CPU fallback)")
+        f32 = torch.float32
+        P, K = self.P, self.K
         shape = self._extended_shape(sample_shape)
-        odx = Categorical(logits=self.offset_logits).expand(shape).sample()
-        val = torch._standard_gamma(conc.expand(shape)) * self.gain
-        return val.clamp(min=torch.finfo(val.dtype).tiny) + self.offset_samples[odx]
+        lead = shape[: len(shape) - len(self.event_shape)]  # sample_shape + batch_shape
+        n = int(torch.Size(lead).numel())
+        m = torch.ones((), device=dev) if self.m is None else self.m
+        if self.alpha is None:
+            # one render unit per batch element, K spots
+            ex = lambda t: t.to(f32).expand(lead + (K,)).reshape(n, K).t().contiguous()
+            h = ex(self.height * m)
+            w, x, y = ex(self.width), ex(self.x), ex(self.y)
+            xy = self.target_locs.to(f32).expand(lead + (2,)).reshape(n, 2).contiguous()
+            b = self.background_.to(f32).expand(lead).reshape(n).contiguous()
+            B, KK = n, K
+        else:
+            # crosstalk: one render unit per (batch element, channel c) with the Q K spots of every dye, heights times alpha_qc
+            Q, Cc = self.Q, self.C
+            hq = (self.height * m).to(f32).expand(lead + (Q, K))  # (..., Q, K)
+            he = hq.unsqueeze(-3) * self.alpha.to(f32).transpose(-1, -2)[..., None]  # (..., C, Q, K)
+            rep = lambda t: t.to(f32).expand(lead + (Q, K)).unsqueeze(-3).expand(lead + (Cc, Q, K))
+            flat = lambda t: t.reshape(n * Cc, Q * K).t().contiguous()
+            h, w, x, y = flat(he), flat(rep(self.width)), flat(rep(self.x)), flat(rep(self.y))
+            xy = self.target_locs.to(f32).expand(lead + (Cc, 2)).reshape(n * Cc, 2).contiguous()
+            b = self.background_.to(f32).expand(lead + (Cc,)).reshape(n * Cc).contiguous()
+            B, KK = n * Cc, Q * K
+        out = torch.empty(B, P, P, dtype=f32, device=dev)
+        gain = self.gain.to(f32).reshape(-1)[:1].contiguous()
+        offs, logits = self.offset_samples.to(f32).contiguous(), self.offset_logits.to(f32).contiguous()
+        a = _lib.RsampleArgs()
+        p = _lib.ptr
+        a.height, a.width, a.x, a.y, a.xy, a.background, a.gain = p(h), p(w), p(x), p(y), p(xy), p(b), p(gain)
+        a.offset_samples, a.offset_logits, a.out = p(offs), p(logits), p(out)
+        a.B, a.P, a.K, a.O = B, P, KK, offs.numel()
+        a.seed = int(torch.randint(0, 2**62, (1,)).item()) if seed is None else int(seed)
+        _lib.check(_lib.load().tq_ksmogn_rsample(C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "tq_ksmogn_rsample")
+        return out.reshape(shape)
 
     sample = rsample
 

@@ -146,6 +146,31 @@ class CosmosEngine:
     def _blk_floats(self, B):
         return int(self.lib.tq_cosmos_blk_floats(self.Nt, self.F, self.C, int(self.crosstalk), B))
 
+    def _run_snr_chi2(self, a):
+        _lib.check(self.lib.tq_snr_chi2(C.byref(a), self._stream()), "tq_snr_chi2")
+
+    def snr_chi2(self, offset_mean, offset_var):
+        """Signal-to-noise ratio of every spot ``(K, Nt, F, Q)`` and chi2 of the fitted image ``(Nt, F, Q)`` at the
+        posterior means of the variational parameters (tapqir/utils/stats.py:29-86, 166-182), computed where the images
+        are: one kernel over all units instead of the reference's host loop over AOIs."""
+        cp = self.layout.constrained(self.params, {"h_loc", "w_mean", "x_mean", "y_mean", "b_loc", "gain_loc"})
+        f32 = torch.float32
+        U = self.Nt * self.F * self.C
+        flat = lambda t: t.detach().to(f32).reshape(self.K, U).contiguous()
+        h, w, x, y = flat(cp["h_loc"]), flat(cp["w_mean"]), flat(cp["x_mean"]), flat(cp["y_mean"])
+        b = cp["b_loc"].detach().to(f32).reshape(U).contiguous()
+        snr = torch.empty(self.K, U, dtype=f32, device=self.device)
+        chi2 = torch.empty(U, dtype=f32, device=self.device)
+        a = _lib.SnrArgs()
+        p = _lib.ptr
+        a.images, a.xy = p(self.images), p(self.xy)
+        a.height, a.width, a.x, a.y, a.background = p(h), p(w), p(x), p(y), p(b)
+        a.snr, a.chi2 = p(snr), p(chi2)
+        a.U, a.P, a.K = U, self.P, self.K
+        a.gain, a.offset_mean, a.offset_var = float(cp["gain_loc"]), float(offset_mean), float(offset_var)
+        self._run_snr_chi2(a)
+        return snr.view(self.K, self.Nt, self.F, self.C), chi2.view(self.Nt, self.F, self.C)
+
     def run_probs(self, a):
         _lib.check(self.lib.tq_cosmos_probs(C.byref(a), self._stream()), "tq_cosmos_probs")
 

@@ -10,6 +10,9 @@ sampled directly with a seeded ``torch.Generator`` on the requested device:
   x_k, y_k ~ AffineBeta(0, size[theta == k+1], -(P+1)/2, (P+1)/2), size = [2, ((P+1)/(2 proximity))^2 - 1]
   image = floor(Gamma(mu / gain, 1 / gain) + offset), mu = background + sum_k m_k h N2(.)
   (crosstalk: mu_c = background + sum_q alpha[q, c] sum_k m_qk h N2(.), params["alpha"] = (Q, C) matrix)
+  kinetic mode (params "kon"/"koff" or "init"/"trans", simulate.py:57-86): z follows a two-state Markov chain over the
+  frames, z_0 ~ [koff, kon] / (kon + koff), P(z_f = 1 | z_{f-1}) = kon (from 0) or 1 - koff (from 1); the rest as above.
+  On a HIP device the images are drawn by ``tq_ksmogn_rsample`` (KSMOGN.rsample), on the CPU by torch's sampler.
 """
 
 import numpy as np
@@ -36,8 +39,9 @@ def simulate(model, N: int, F: int, C: int = 1, P: int = 14, seed: int = 0, para
     """
     K = model if isinstance(model, int) else model.K
     device = torch.device("cpu") if isinstance(model, int) else torch.device(model.device)
-    if "pi" not in params:
-        raise NotImplementedError("only the time-independent laws (cosmos, crosstalk) are generated here")
+    kinetic = ("kon" in params and "koff" in params) or ("init" in params and "trans" in params)
+    if "pi" not in params and not kinetic:
+        raise ValueError('simulate needs "pi" (time-independent law), or "kon"/"koff" or "init"/"trans" (kinetic law)')
     # crosstalk simulations (simulate.py:27-31, 118-123): params["alpha"] is the (Q, C) matrix of the fraction of dye
     # q's signal seen in channel c (crosstalk.py:262-281)
     alpha = None
@@ -54,7 +58,27 @@ def simulate(model, N: int, F: int, C: int = 1, P: int = 14, seed: int = 0, para
     target = torch.full((N, F, C, 2), (P - 1) / 2, dtype=dt)
 
     u = lambda *s: torch.rand(*s, generator=gen, device=device, dtype=dt)
-    z = (u(N, F, Q) < params["pi"]) & on[:, None, None]
+    if "pi" in params:
+        z = (u(N, F, Q) < params["pi"]) & on[:, None, None]
+    else:
+        # kinetic simulations (simulate.py:57-86; the frames of the reference's cosmos+hmm model, hmm.py:151-176, 258):
+        # z_0 ~ Categorical(init), z_f | z_{f-1} ~ Categorical(trans[z_{f-1}]) for the on-target AOIs, z = 0 off-target
+        # (expand_offtarget); every frame then follows the time-independent law given z
+        if "kon" in params:
+            kon, koff = float(params["kon"]), float(params["koff"])
+            p_init, p01, p11 = kon / (kon + koff), kon, 1.0 - koff
+        else:
+            init = torch.as_tensor(params["init"], dtype=torch.float64).reshape(-1, 2)[0]
+            trans = torch.as_tensor(params["trans"], dtype=torch.float64).reshape(-1, 2, 2)[0]
+            p_init, p01, p11 = float(init[1]), float(trans[0, 1]), float(trans[1, 1])
+        uz = u(N, F, Q)
+        z = torch.zeros(N, F, Q, dtype=torch.bool, device=device)
+        prev = uz[:, 0] < p_init
+        z[:, 0] = prev
+        for f in range(1, F):
+            prev = uz[:, f] < torch.where(prev, torch.tensor(p11, dtype=dt, device=device), torch.tensor(p01, dtype=dt, device=device))
+            z[:, f] = prev
+        z &= on[:, None, None]
     theta = torch.where(z, 1 + (u(N, F, Q) * K).long().clamp(max=K - 1), torch.zeros((), dtype=torch.long, device=device))
     pm = probs_m(torch.tensor(float(params["lamda"]), dtype=torch.float64), K).to(dt).to(device)  # (1+K, K)
     m = u(N, F, Q, K) < pm[theta]  # (N,F,Q,K)
@@ -68,8 +92,27 @@ def simulate(model, N: int, F: int, C: int = 1, P: int = 14, seed: int = 0, para
     h = torch.tensor(float(params["height"]), dtype=dt, device=device)
     w = torch.tensor(float(params["width"]), dtype=dt, device=device)
     gain = float(params["gain"])
+    offs3 = torch.full((3,), float(params["offset"]), dtype=dt, device=device)
+    logit3 = torch.full((3,), -float(np.log(3.0)), dtype=dt, device=device)
     for s in range(0, N, chunk):
         sl = slice(s, min(N, s + chunk))
+        if device.type == "cuda":
+            # the reference draws the images with KSMOGN.rsample (simulate.py:108-111 -> ksmogn.py:171-185): on the GPU
+            # that is tq_ksmogn_rsample; seeds follow the generator of this call
+            from tapqir_amd.distributions.ksmogn import KSMOGN
+
+            n = sl.stop - sl.start
+            seed_s = int(torch.randint(0, 2**62, (1,), generator=gen, device=device).item())
+            if alpha is None:
+                d = KSMOGN(h.expand_as(x[sl]), w.expand_as(x[sl]), x[sl], y[sl], target[sl].to(device),
+                           torch.full((n, F, C), float(params["background"]), dtype=dt, device=device),
+                           torch.tensor(gain, dtype=dt, device=device), offs3, logit3, P, m=m[sl].to(dt))
+            else:
+                d = KSMOGN(h.expand_as(x[sl]), w.expand_as(x[sl]), x[sl], y[sl], target[sl].to(device),
+                           torch.full((n, F, C), float(params["background"]), dtype=dt, device=device),
+                           torch.tensor(gain, dtype=dt, device=device), offs3, logit3, P, m=m[sl].to(dt), alpha=alpha)
+            images[sl] = d.rsample(seed=seed_s).floor().cpu()
+            continue
         tl = target[sl].to(device)[..., None, :]
         spots = gaussian_spots(h.expand_as(x[sl]), w.expand_as(x[sl]), x[sl], y[sl], tl, P, m[sl].to(dt))
         mu = spots.sum(-3)  # (n, F, Q, P, P)

@@ -3,8 +3,9 @@ Post-fit statistics (the part of tapqir/utils/stats.py:89-259 that `tapqir fit` 
 intervals of the variational posteriors (scipy), spot probabilities, classification scores against
 simulated labels, ``<name>_params.tpqr`` / ``<name>_summary.csv`` (/ ``.mat``).
 
-Runs once per fit on the host: credible intervals, SNR and chi2 (stats.py:29-86, 166-193), plot ranges, classification
-scores and p(specific) (194-226).  The rastergram PNGs of the reference (105-124) are not drawn.
+Runs once per fit: credible intervals (scipy, host), SNR and chi2 (stats.py:29-86, 166-193; ``tq_snr_chi2`` on the device
+through ``CosmosEngine.snr_chi2``), plot ranges, classification scores and p(specific) (194-226).  The rastergram PNGs of the
+reference (105-124) are not drawn.
 """
 
 import logging
@@ -59,21 +60,37 @@ def hpdi(x, prob):
     return left[i], right[i]
 
 
-def snr_and_chi2(data, height, width, x, y, target_locs, background, gain, offset_mean, offset_var, P):
-    """Signal-to-noise ratio of each spot and chi2 of the fitted image for the frames of one AOI (stats.py:29-86).
+def snr_and_chi2(data, height, width, x, y, target_locs, background, gain, offset_mean, offset_var, P, theta_probs=None):
+    """Signal-to-noise ratio of each spot and chi2 of the fitted image (same arguments as tapqir/utils/stats.py:29-86;
+    ``theta_probs`` is accepted and unused there too), evaluated by ``tq_snr_chi2`` on the HIP device.
 
-    data (F, C, P, P); height/width/x/y (K, F, Q); target_locs (F, C, 2); background (F, C).
+    data (..., C, P, P); height / width / x / y (K, ..., Q); target_locs (..., C, 2); background (..., C) with Q = C:
     signal_k = sum_ij (D - b - offset_mean) N_k(i, j),  noise = sqrt(offset_var + b gain),  SNR = signal / noise;
     chi2 = mean_ij (D - ideal - offset_mean)^2 / ideal,  ideal = b + sum_k h_k N_k."""
-    from tapqir_amd.distributions.util import gaussian_spots
+    import ctypes as C
 
-    g = gaussian_spots(height, width, x, y, target_locs, P)  # (K, F, Q, P, P): the last parameter dim acts as "K"
-    weights = g / height[..., None, None]
-    resid = data - background[..., None, None] - offset_mean
-    snr = (resid * weights).sum((-2, -1)) / (offset_var + background * gain).sqrt()
-    ideal = background[..., None, None] + g.sum(-5)
-    chi2 = ((data - ideal - offset_mean) ** 2 / ideal).mean((-1, -2))
-    return snr, chi2
+    from tapqir_amd import _lib
+    from tapqir_amd.exceptions import HipExtensionError
+
+    if data.device.type != "cuda":
+        raise HipExtensionError("snr_and_chi2 runs on the HIP device only (no CPU fallback)")
+    f32, dev = torch.float32, data.device
+    K, lead = height.shape[0], data.shape[:-2]
+    U = int(torch.Size(lead).numel())
+    flat = lambda t: t.to(dev, f32).expand((K,) + lead).reshape(K, U).contiguous()
+    img = data.to(f32).contiguous()
+    xy = target_locs.to(dev, f32).expand(lead + (2,)).contiguous()
+    h, w, xx, yy = flat(height), flat(width), flat(x), flat(y)
+    b = background.to(dev, f32).expand(lead).reshape(U).contiguous()
+    snr = torch.empty(K, U, dtype=f32, device=dev)
+    chi2 = torch.empty(U, dtype=f32, device=dev)
+    a = _lib.SnrArgs()
+    p = _lib.ptr
+    a.images, a.xy, a.height, a.width, a.x, a.y, a.background = p(img), p(xy), p(h), p(w), p(xx), p(yy), p(b)
+    a.snr, a.chi2, a.U, a.P, a.K = p(snr), p(chi2), U, int(P), K
+    a.gain, a.offset_mean, a.offset_var = float(gain), float(offset_mean), float(offset_var)
+    _lib.check(_lib.load().tq_snr_chi2(C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "tq_snr_chi2")
+    return snr.reshape((K,) + lead), chi2.reshape(lead)
 
 
 def save_stats(model, path, CI=0.95, save_matlab=False):
@@ -105,14 +122,9 @@ def save_stats(model, path, CI=0.95, save_matlab=False):
 
     logger.info("- SNR and Chi2-test")
     K, Q = model.K, model.Q
-    images, xy = data.images.cpu().double(), data.xy.cpu().double()
-    snr = torch.zeros(K, data.Nt, data.F, Q, dtype=torch.float64)
-    chi2 = torch.zeros(data.Nt, data.F, Q, dtype=torch.float64)
-    mean = lambda n: ci_stats[n]["Mean"].double()
-    for n in range(data.Nt):
-        snr[:, n], chi2[n] = snr_and_chi2(images[n], mean("height")[:, n], mean("width")[:, n], mean("x")[:, n],
-                                          mean("y")[:, n], xy[n], mean("background")[n], mean("gain"),
-                                          data.offset.mean, data.offset.var, data.P)
+    # one kernel over all units on the device that holds the images (stats.py:166-182 loops over the AOIs on the host)
+    snr, chi2 = model.engine.snr_chi2(data.offset.mean, data.offset.var)
+    snr, chi2 = snr.double().cpu(), chi2.double().cpu()
     for q in range(Q):
         sel = snr[..., q][ci_stats["theta_probs"][..., q] > 0.5]
         summary.loc[f"SNR_{q}", "Mean"] = float(sel.mean()) if sel.numel() else float("nan")

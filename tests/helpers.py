@@ -43,6 +43,10 @@ def load_hostcheck():
     lib.hc_ksmogn_crosstalk_log_prob.argtypes = [C.POINTER(_lib.XtalkArgs)]
     lib.hc_image_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     lib.hc_image_stats.restype = None
+    lib.hc_snr_chi2.argtypes = [C.POINTER(_lib.SnrArgs)]
+    lib.hc_snr_chi2.restype = None
+    lib.hc_ksmogn_rsample.argtypes = [C.POINTER(_lib.RsampleArgs)]
+    lib.hc_ksmogn_rsample.restype = None
     lib.hc_cosmos_probs.argtypes = [C.POINTER(_lib.ProbsArgs)]
     lib.hc_cosmos_probs.restype = None
     for n in ("hc_cosmos_sample_globals", "hc_cosmos_sample_locals", "hc_cosmos_elbo_grads",
@@ -96,6 +100,9 @@ class HostCheckEngine(HipEngine):
 
     def run_probs(self, a):
         self.lib.hc_cosmos_probs(C.byref(a))
+
+    def _run_snr_chi2(self, a):
+        self.lib.hc_snr_chi2(C.byref(a))
 
 
 def CosmosEngine(data, lib=None, **kw):

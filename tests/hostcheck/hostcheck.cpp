@@ -11,6 +11,7 @@
 
 #include "../../tapqir_amd/csrc/tq_bodies.h"
 #include "../../tapqir_amd/csrc/tq_pixel.h"
+#include "../../tapqir_amd/csrc/tq_aux.h"
 #include "../../tapqir_amd/csrc/tq_xtalk.h"
 
 extern "C" {
@@ -406,4 +407,14 @@ extern "C" void hc_cosmos_probs(const tq_probs_args* a) {
     case 3: probs_host<3>(*a); break;
     default: probs_host<4>(*a); break;
   }
+}
+
+// ---- off-step bodies (tq_aux.h) ------------------------------------------------------------------------------------
+extern "C" void hc_ksmogn_rsample(const tq_rsample_args* a) {
+  const int npix = a->P * a->P;
+  for (int64_t i = 0; i < a->B; ++i)
+    for (int p = 0; p < npix; ++p) tq_body_rsample(*a, i, p);
+}
+extern "C" void hc_snr_chi2(const tq_snr_args* a) {
+  for (int64_t u = 0; u < a->U; ++u) tq_body_snr_chi2(*a, u);
 }

@@ -119,9 +119,11 @@ def test_fit_checkpoint_resume_and_stats_on_device(tmp_path):
 
 
 def test_snr_chi2_quantile_hpdi():
-    """stats.py:29-86 on a noiseless image: chi2 = 0 and SNR = h sum(N^2) / sqrt(offset_var + b gain)."""
-    from tapqir_amd.distributions.util import gaussian_spots
-    from tapqir_amd.utils.stats import hpdi, quantile, snr_and_chi2
+    """stats.py:29-86 on a noiseless image: chi2 = 0 and SNR = h sum(N^2) / sqrt(offset_var + b gain) (oracle restatement;
+    the kernel is compared with it in tests/test_aux.py)."""
+    from oracle.dist_util import gaussian_spots
+    from oracle.stats import snr_and_chi2
+    from tapqir_amd.utils.stats import hpdi, quantile
 
     K, F, Q, P = 2, 3, 1, 14
     h = torch.tensor([3000.0, 1500.0]).double().reshape(K, 1, 1).expand(K, F, Q)
@@ -249,3 +251,28 @@ def test_stats_with_on_and_off_target_labels(tmp_path):
     m.run(2, progress_bar=lambda r: r)
     m.compute_stats()
     assert "MCC" in m.summary.index and (tmp_path / "cosmos_summary.csv").is_file()
+
+
+def test_simulate_kinetic_mode():
+    """simulate.py:66-86: with kon / koff the labels follow a two-state Markov chain over the frames."""
+    p = dict(TEST_PARAMS)
+    del p["pi"]
+    p.update(kon=0.05, koff=0.2)
+    d = simulate(2, 80, 400, 1, 14, 0, p)
+    z = torch.from_numpy(d.labels["z"][..., 0]).double()  # (N_on, F)
+    assert z.shape == (40, 400)
+    assert abs(float(z.mean()) - 0.05 / 0.25) < 0.02  # stationary occupancy kon / (kon + koff)
+    on_to_off = ((z[:, :-1] == 1) & (z[:, 1:] == 0)).double().sum() / (z[:, :-1] == 1).double().sum()
+    off_to_on = ((z[:, :-1] == 0) & (z[:, 1:] == 1)).double().sum() / (z[:, :-1] == 0).double().sum()
+    assert abs(float(on_to_off) - 0.2) < 0.02 and abs(float(off_to_on) - 0.05) < 0.006
+    # frames with a target-specific spot are brighter at the target
+    img = d.images[:40, :, 0, 6:8, 6:8].mean((-1, -2))
+    assert float(img[z == 1].mean()) > float(img[z == 0].mean()) + 50
+    # the explicit init / trans spelling (simulate.py:57-64) gives the same chain law
+    p2 = dict(TEST_PARAMS)
+    del p2["pi"]
+    p2.update(init=torch.tensor([[0.8, 0.2]]), trans=torch.tensor([[[0.95, 0.05], [0.2, 0.8]]]))
+    d2 = simulate(2, 80, 400, 1, 14, 0, p2)
+    assert torch.equal(torch.from_numpy(d2.labels["z"]), torch.from_numpy(d.labels["z"]))
+    with pytest.raises(ValueError):
+        simulate(2, 4, 4, 1, 14, 0, {k: v for k, v in TEST_PARAMS.items() if k != "pi"})
