@@ -240,33 +240,33 @@ def time_pixel_kernel(eng, launches, backward):
     K, M = eng.K, 1 << eng.K
     B = eng.Nt * eng.F * eng.C
     xt = eng.crosstalk
-    k = _lib.XtalkArgs() if xt else _lib.KsmognArgs()
-    p = _lib.ptr
-    k.images, k.images_il, k.xy, k.ndx, k.fdx = p(eng.images), p(eng.images_il), p(eng.xy), None, None
-    k.nb_full, k.il_min_units = eng.Nt, eng.il_min_units
-    k.pixstats = p(eng.pixstats)
-    lat = eng.lat
-    f = lambda row: lat.data_ptr() + 4 * row * B
-    k.background, k.height, k.width, k.x, k.y = f(0), f(1), f(1 + K), f(1 + 2 * K), f(1 + 3 * K)
-    k.gain = eng.globals.data_ptr()
-    k.offset_samples, k.offset_logits = p(eng.offset_samples), p(eng.offset_logits)
-    k.gout, k.m_logit, k.aoi_mask = None, p(eng.params), p(eng.mask)
-    pix = eng.pix
-    g = lambda row: pix.data_ptr() + 4 * row * B
-    k.ll = g(0)
-    if xt:
+    if not xt:
+        k = eng.ksmogn_args(backward)  # the form (pixel_mode) the engine chose for this box
+    else:
+        k = _lib.XtalkArgs()
+        p = _lib.ptr
+        k.images, k.images_il, k.xy, k.ndx, k.fdx = p(eng.images), p(eng.images_il), p(eng.xy), None, None
+        k.nb_full, k.il_min_units = eng.Nt, eng.il_min_units
+        k.pixstats = p(eng.pixstats)
+        lat = eng.lat
+        f = lambda row: lat.data_ptr() + 4 * row * B
+        k.background, k.height, k.width, k.x, k.y = f(0), f(1), f(1 + K), f(1 + 2 * K), f(1 + 3 * K)
+        k.gain = eng.globals.data_ptr()
+        k.offset_samples, k.offset_logits = p(eng.offset_samples), p(eng.offset_logits)
+        k.gout, k.m_logit, k.aoi_mask = None, p(eng.params), p(eng._mask_arg)
+        pix = eng.pix
+        g = lambda row: pix.data_ptr() + 4 * row * B
+        k.ll = g(0)
         k.alpha = eng.globals.data_ptr() + 4 * 21  # TqGlobals.alpha (tq_site.h)
         k.ll_joint = None
         k.ell_excess = g(M + 2 + 4 * K)
         k.g_alpha = g(M + 3 + 4 * K)
-    else:
-        k.stats_stride = B
-    if backward:
-        k.g_background, k.g_gain = g(M), g(M + 1)
-        k.g_height, k.g_width, k.g_x, k.g_y = g(M + 2), g(M + 2 + K), g(M + 2 + 2 * K), g(M + 2 + 3 * K)
-    k.m_kstride = B
-    k.nb, k.fb, k.C, k.F, k.P, k.K, k.O = eng.Nt, eng.F, eng.C, eng.F, eng.P, K, eng.O
-    k.scale = 1.0
+        if backward:
+            k.g_background, k.g_gain = g(M), g(M + 1)
+            k.g_height, k.g_width, k.g_x, k.g_y = g(M + 2), g(M + 2 + K), g(M + 2 + 2 * K), g(M + 2 + 3 * K)
+        k.m_kstride = B
+        k.nb, k.fb, k.C, k.F, k.P, k.K, k.O = eng.Nt, eng.F, eng.C, eng.F, eng.P, K, eng.O
+        k.scale = 1.0
     fn = eng.lib.tq_ksmogn_crosstalk_log_prob if xt else eng.lib.tq_ksmogn_log_prob
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
@@ -337,7 +337,9 @@ def roofline_block(pb, ms_per_step, dev):
         kernel = "tq_xtalk_il_kernel<K,P,bwd> (coupled-dye render + log-prob of the 2^(KQ) joint combinations + pathwise grads)"
     else:
         bpu = fwd_bytes_per_unit(K, P)
-        kernel = "tq_ksmogn_il2_kernel<K,P,bwd> (fused render + log-prob + pathwise grads; packed lane-per-unit)" \
+        kernel = (("tq_ksmogn_il2p_kernel<K,P,bwd> (persistent form" if eng.pixel_mode else "tq_ksmogn_il2_kernel<K,P,bwd> (one wave per tile")
+                  + "; fused render + log-prob + pathwise grads, packed lane-per-unit; form chosen by timing both on this box: "
+                  + str([round(t, 4) for t in getattr(eng, "pixel_times_ms", [])]) + " ms)") \
             if eng.O == 1 else "tq_ksmogn_il2m_kernel<K,bwd> (offset-histogram form of the same kernel)"
     ach = units * bpu / t_fb / 1e9
     traffic, tsrc = (pmc_traffic(K, P, units, True) if (pb.offsets == "sim" and not eng.crosstalk) else (None, None))

@@ -88,6 +88,9 @@ typedef struct {
   int32_t nb_full;             /* Nt of the dataset behind images_il */
   int32_t il_min_units;        /* use the interleaved kernel only for batches of at least this many units */
   float scale;                 /* plate scale (Nt/nb)(F/fb), used with m_logit */
+  int32_t pixel_mode;          /* backward pass on the interleaved layout (K <= 2, one offset): 1 = persistent waves that walk
+                                  over the tiles with every global read an LDS-DMA request, 0 = one wave per tile.  Same
+                                  results; which is faster depends on the box, so the host times both once */
 } tq_ksmogn_args;
 
 int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
@@ -244,6 +247,7 @@ typedef struct {
   /* lazy Adam of minibatch steps (tq_cosmos_adam_catchup) */
   int32_t* last_step;          /* [Nt*F*C] Adam step at which the local parameters of a unit were last updated, or NULL */
   double beta1_d, beta2_d;     /* the Adam betas in double: 1 - beta^s of the replayed steps is formed like the host's */
+  int32_t pixel_mode;          /* passed on to tq_ksmogn_args.pixel_mode */
 } tq_cosmos_args;
 
 int64_t tq_globals_size(void);

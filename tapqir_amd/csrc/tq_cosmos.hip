@@ -446,6 +446,7 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   k.pixstats = a->pixstats;
   k.stats_stride = U;
   k.il_min_units = a->il_min_units;  // below ~1 wave per SIMD the 16-lanes-per-unit kernel has more parallelism
+  k.pixel_mode = a->pixel_mode;
   k.background = a->lat;
   k.height = a->lat + (int64_t)1 * B;
   k.width = a->lat + (int64_t)(1 + K) * B;

@@ -152,11 +152,13 @@ __device__ __forceinline__ void tq_pixel_multi_offset(TqPixAcc<K>& A, const tq_k
 template <int K, bool BWD>
 __device__ __forceinline__ void tq_pixel_assemble_one_offset(const tq_ksmogn_args& a, TqPixAcc<K>& A, const float* W,
                                                              float b, float g, float rg, float ln_g, float fnpix,
-                                                             float S_v, float S_lv) {
+                                                             float S_v, float S_lv, const float* logit0 = nullptr) {
+  // logit0: the log-weight of the single offset if the caller has it in a register (the persistent kernel keeps
+  // register-destination loads out of its tile loop)
   constexpr int M = 1 << K;
   TqCombo0 c0;
   tq_combo0_prepare(b, rg, g, ln_g, &c0);
-  const float lw0 = a.offset_logits[0] - TQ_LN_SQRT_2PI;
+  const float lw0 = (logit0 ? *logit0 : a.offset_logits[0]) - TQ_LN_SQRT_2PI;
   const float common = lw0 * fnpix - S_lv;             // sum [ln w - ln sqrt(2pi) - ln v]
   const float S_lvg = S_lv - fnpix * ln_g;             // sum [ln v - ln g]
   const float sl0 = S_lv - fnpix * c0.lnb;             // sum ln(v / b)
@@ -567,7 +569,9 @@ struct TqFastConst {
 template <int K, int P, bool BWD, bool COLACC>
 __device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 v, float b, const tq_f2* spot,
                                               const float* W, const int ip, const bool first_in_row,
-                                              const TqFastConst& c) {
+                                              const float c_ca, const float c_cb, const float c_s1, const float c_s3,
+                                              const float c_d1, const float c_d2, const float c_d4) {
+  // (the constants of TqFastConst as scalars: as a struct they end up in scratch in some instantiations)
   constexpr int M = 1 << K;
   tq_f2 da[M];
   tq_f2 mus[M];
@@ -580,9 +584,9 @@ __device__ __forceinline__ void tq_pixel_pair(TqPixAcc2<K, P, COLACC>& A, tq_f2 
     const tq_f2 r = tq2_rcp(mus[mi]);
     const tq_f2 l2 = tq2_log2(v * r);
     const tq_f2 u = r * r;
-    A.T[mi] += (mus[mi] * c.ca - c.cb) * l2;
-    A.T[mi] -= r * (u * c.s3 + c.s1);
-    if (BWD) da[mi] = r * (r * (u * c.d4 + c.d2) + c.d1) + l2;  // = da / ln2
+    A.T[mi] += (mus[mi] * c_ca - c_cb) * l2;
+    A.T[mi] -= r * (u * c_s3 + c_s1);
+    if (BWD) da[mi] = r * (r * (u * c_d4 + c_d2) + c_d1) + l2;  // = da / ln2
   }
   if (BWD) {
     // q_k = sum_{m containing k} W_m da_m,  acc_b += sum_m W_m da_m
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
           tq_f2 spot[K];
 #pragma unroll
           for (int k = 0; k < K; ++k) spot[k] = agy[k] * ex[k][ip];
-          tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c);
+          tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c.ca, c.cb, c.s1, c.s3, c.d1, c.d2, c.d4);
         }
         if (BWD) {
           // y-moments about the spot's own centre (the row offset dy is at hand): no cancellation later
@@ -821,42 +825,76 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2_kernel(con
 // =============================================================================================
 // Persistent form of the packed kernel (backward pass of full-batch steps).
 //
-// tq_ksmogn_il2_kernel spends ~7 us per round of its one-wave workgroups outside the pixel loop: a fresh wave waits for
-// its unit parameters (one HBM round trip), computes the x-factor table, runs the loop, then waits again for the data
-// statistics before it can store -- and with two waves per SIMD only the sibling wave can cover that.  Here a wave
-// stays resident and walks over tiles (tile = 64 units): while it runs the LAST loop body of a tile, the next tile's
-// per-unit scalars (target position, draws, m_probs logits, data statistics: 6 + 5K dwords per unit) stream into a
-// wave-private LDS slab by LDS-DMA (global_load_lds_dword: no VGPRs, nothing to spill at 216 registers) and the image
-// ring is refilled with the next tile's first groups, so a tile starts from LDS reads and registers that are already
-// full.  Two slabs alternate: the epilogue of tile t still reads slab t (spot heights / widths, statistics).
-// The compiler does not order LDS reads behind LDS-DMA writes: the explicit vmcnt(0) at the top of a tile does.
+// tq_ksmogn_il2_kernel spends ~7 us per round of its one-wave workgroups outside the pixel loop (a fresh wave waits for
+// its unit parameters, computes the x-factor table, runs the loop, waits again for the data statistics before it can
+// store) and, inside the loop, waits for ALL image loads of a body at its top (the waits the compiler derives for
+// register-destination loads degrade to vmcnt(0) as soon as the loop is not the peeled single-tile form).  Here
+//   * a wave stays resident and walks over tiles (tile = 64 units);
+//   * EVERY global read of the hot path is an LDS-DMA request (global_load_lds_*: memory -> LDS, no VGPRs) issued
+//     through inline assembly, so the compiler neither tracks nor waits for them and the waits are written by hand:
+//       - the image stream runs through a ring of 8 slots x 1 KiB in LDS, 8 groups (32 pixels per lane) ahead of the
+//         arithmetic: a group is read back with one ds_read_b128 and its slot is refilled at once;
+//       - the next tile's per-unit scalars (target position, draws, m_probs logits, data statistics: 6 + 5K dwords
+//         per unit) stream into one of two wave-private slabs while the last body of the current tile runs.
+//   * vector-memory operations complete in issue order, so "the request for group q has landed" is s_waitcnt vmcnt(N)
+//     with N = the number of requests issued after it: always the 7 younger ring requests, plus the 6 + 5K scalar
+//     requests inside the last body, plus the result stores of the previous tile in the first body.  The request
+//     pattern is kept identical in the last tile (dummy requests to valid addresses) so that N never overstates.
 // =============================================================================================
 #define TQ_P_NPAR(K) (6 + 5 * (K))
-#ifndef TQ_P_DMA_EARLY
-#define TQ_P_DMA_EARLY 1
+#ifndef TQ_P_NSLOT
+#define TQ_P_NSLOT 8  // ring slots = groups the image stream runs ahead
+#endif
+#ifndef TQ_P_WAVES
+#define TQ_P_WAVES 2  // resident waves per SIMD the register allocation is sized for (K <= 3)
+#endif
+#ifndef TQ_P_COLACC
+#define TQ_P_COLACC 1  // x-moments as per-column sums (K * P / 2 float2 registers for two packed instructions per pair and spot)
 #endif
 
+__device__ __forceinline__ uint32_t tq_lds_addr(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// memory -> LDS, 4 / 16 bytes per lane: lane l reads base + voff and writes LDS byte lds + l * 4 (16)
+__device__ __forceinline__ void tq_dma4(const void* base, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void tq_dma16(const void* base, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tq_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int K, int P, bool BWD>
-__global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(const tq_ksmogn_args a, const int64_t B,
-                                                                              const int ntiles) {
+__global__ __launch_bounds__(64, (K <= 3 ? TQ_P_WAVES : 1)) void tq_ksmogn_il2p_kernel(const tq_ksmogn_args a, const int64_t B,
+                                                                              const int64_t Bn, const int ntiles) {
+  // B = units of the batch (row stride of the [K][B] arrays); Bn <= B = units this launch covers (tiles 0 .. ntiles-1)
   static_assert(P % 2 == 0 && (P * P) % 4 == 0, "packed kernel needs an even tile side");
   constexpr int M = 1 << K;
-  constexpr int R = ((P / 2) % 2) ? 2 : 1;
-  constexpr int G = R * P / 4;
-  constexpr int NB = P / R;
-  constexpr int npix = P * P, npix4 = npix / 4;
-  constexpr bool COLACC = BWD && (K * P <= 28);
-  constexpr int NPAR = TQ_P_NPAR(K);
+  constexpr int R = ((P / 2) % 2) ? 2 : 1;  // rows per loop body so that the body starts on a float4 boundary
+  constexpr int G = R * P / 4;              // float4 groups per body
+  constexpr int NB = P / R;                 // bodies per tile
+  constexpr int npix = P * P, NG = npix / 4;
+  constexpr bool COLACC = BWD && (K * P <= 28) && TQ_P_COLACC;
+  constexpr int NPAR = TQ_P_NPAR(K), NSLOT = TQ_P_NSLOT;
+  constexpr int NSTORE = BWD ? M + 2 + 4 * K : M;  // result stores of a tile (vector-memory operations, in issue order)
+  static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT <= NG && NB >= 3, "ring slots: a power of two");
   // slab rows: 0 tx, 1 ty, 2 b, 3.. h[K], w[K], x[K], y[K], m_logit[K], then the 3 data statistics
   constexpr int R_H = 3, R_W = 3 + K, R_X = 3 + 2 * K, R_Y = 3 + 3 * K, R_M = 3 + 4 * K, R_S = 3 + 5 * K;
+  __shared__ float4 s_ring[NSLOT][64];
   __shared__ float s_par[2][NPAR][64];
   const int lane = threadIdx.x;
+  const uint32_t ring_lds = tq_lds_addr(&s_ring[0][0]), par_lds = tq_lds_addr(&s_par[0][0][0]);
   const float4* il = reinterpret_cast<const float4*>(a.images_il);
 
   const float g = a.gain[0];
   const float rg = TQ_FRCP(g);
   const float ln_g = TQ_FLOG(g);
   const float off0 = a.offset_samples[0];
+  const float logit0 = a.offset_logits[0];
   TqFastConst c;
   {
     const float g2 = g * g, rl2 = 1.0f / TQ_LN2;
@@ -870,52 +908,51 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(co
   }
   const float sc_plate = a.scale;
 
-  // per-unit scalars of tile `t` -> slab `buf` (LDS-DMA; lanes beyond B shadow the last unit)
-  auto prefetch_params = [&](const int t, const int buf) {
-    // wave-uniform row base (scalar registers) + one 32-bit lane offset: the 6 + 5K requests share a single address VGPR
+  // per-unit scalars of tile `t` -> slab `buf`: NPAR requests (lanes beyond Bn shadow the last unit)
+  auto request_params = [&](const int t, const int buf) __attribute__((always_inline)) {
     const int64_t t0 = (int64_t)t * 64;
-    const int64_t rem = B - 1 - t0;  // >= 0: t < ntiles
+    const int64_t rem = Bn - 1 - t0;  // >= 0: t < ntiles
     const uint32_t l = (uint32_t)lane < (uint32_t)rem ? (uint32_t)lane : (uint32_t)rem;
-    typedef const __attribute__((address_space(1))) void* gptr;
-    typedef __attribute__((address_space(3))) void* lptr;
-    auto put = [&](const float* row_base, const uint32_t off, const int row) {
-      __builtin_amdgcn_global_load_lds((gptr)(row_base + off), (lptr)&s_par[buf][row][0], 4, 0, 0);
-    };
-    put(a.xy + 2 * t0, 2 * l, 0);
-    put(a.xy + 2 * t0 + 1, 2 * l, 1);
-    put(a.background + t0, l, 2);
+    const uint32_t slab = par_lds + (uint32_t)buf * (NPAR * 256);
+    auto put = [&](const float* row_base, const uint32_t off_bytes, const int row) { tq_dma4(row_base, off_bytes, slab + row * 256); };
+    put(a.xy + 2 * t0, 8 * l, 0);
+    put(a.xy + 2 * t0 + 1, 8 * l, 1);
+    put(a.background + t0, 4 * l, 2);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      put(a.height + k * B + t0, l, R_H + k);
-      put(a.width + k * B + t0, l, R_W + k);
-      put(a.x + k * B + t0, l, R_X + k);
-      put(a.y + k * B + t0, l, R_Y + k);
-      put(a.m_logit + k * a.m_kstride + t0, l, R_M + k);
+      put(a.height + k * B + t0, 4 * l, R_H + k);
+      put(a.width + k * B + t0, 4 * l, R_W + k);
+      put(a.x + k * B + t0, 4 * l, R_X + k);
+      put(a.y + k * B + t0, 4 * l, R_Y + k);
+      put(a.m_logit + k * a.m_kstride + t0, 4 * l, R_M + k);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) put(a.pixstats + j * a.stats_stride + t0, l, R_S + j);
+    for (int j = 0; j < 3; ++j) put(a.pixstats + j * a.stats_stride + t0, 4 * l, R_S + j);
+  };
+  // group `j` (4 pixels of each of the 64 units) of tile `t` -> ring slot `slot`
+  const uint32_t lane16 = (uint32_t)lane * 16;
+  auto request_group = [&](const int t, const int j, const int slot) __attribute__((always_inline)) {
+    tq_dma16(il + ((int64_t)t * NG + j) * 64, lane16, ring_lds + (uint32_t)slot * 1024);
   };
 
   int t = blockIdx.x;
   if (t >= ntiles) return;
-  prefetch_params(t, 0);
-  float4 ring[G];
-  {
-    const float4* src0 = il + ((int64_t)t * npix4) * 64 + lane;
+  request_params(t, 0);
 #pragma unroll
-    for (int j = 0; j < G; ++j) ring[j] = src0[j * 64];
-  }
-  int buf = 0;
-  for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+  for (int j = 0; j < NSLOT; ++j) request_group(t, j, j);
+  tq_wait_vm<0>();  // once per wave; afterwards the counts below are exact or understate
+  int buf = 0, slot0 = 0;  // slab of the current tile; ring slot of its group 0
+  bool first = true;
+  for (; t < ntiles; t += gridDim.x, buf ^= 1, slot0 = (slot0 + NG) & (NSLOT - 1)) {
     const int tn = t + (int)gridDim.x;
-    const bool has_next = tn < ntiles;
+    const int tnx = tn < ntiles ? tn : t;  // no next tile: the same requests go to this tile's (valid) addresses
     const int64_t i_raw = (int64_t)t * 64 + lane;
-    const bool live = i_raw < B;
-    const int64_t i = live ? i_raw : (B - 1);
-    const float4* src = il + ((int64_t)t * npix4) * 64 + lane;
-    const float4* src_next = il + ((int64_t)(has_next ? tn : t) * npix4) * 64 + lane;
-    // the slab of this tile was requested one loop body ago (or before the loop)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool live = i_raw < Bn;
+    const int64_t i = live ? i_raw : (Bn - 1);
+    // the slab of this tile was requested at the top of the previous tile's last body: G ring requests and that tile's
+    // result stores are younger
+    if (!first) tq_wait_vm<G + NSTORE>();
+    first = false;
     const float (*sp)[64] = s_par[buf];
     const float tx = sp[0][lane], ty = sp[1][lane];
     const float b = sp[2][lane];
@@ -940,8 +977,11 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(co
         p1[k] = tq_fast_sigmoid(uk);
         p0[k] = tq_fast_sigmoid(-uk);
       }
-      const int n = (int)((uint32_t)i / (uint32_t)(a.F * a.C));
-      const float sc = sc_plate * ((a.aoi_mask == nullptr || a.aoi_mask[n]) ? 1.0f : 0.0f);
+      float sc = sc_plate;
+      if (a.aoi_mask != nullptr) {  // (the host passes NULL when no AOI is masked: a register-destination load and its wait)
+        const int n = (int)((uint32_t)i / (uint32_t)(a.F * a.C));
+        sc = a.aoi_mask[n] ? sc_plate : 0.0f;
+      }
 #pragma unroll
       for (int mi = 0; mi < M; ++mi) {
         float w = sc;
@@ -981,16 +1021,12 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(co
           for (int ip = 0; ip < P / 2; ++ip) A.col[k][ip] = tq2(0.0f);
         }
       }
-      // one loop body = R rows; the groups of the following body (of the next tile's first body in the last one) are
-      // fetched as those of this one retire.  TQ_P_DMA_EARLY: the next tile's scalars are requested at the top of the last
-      // body (a whole body of cover) instead of after it (cover = the epilogue)
-#pragma unroll 1
-      for (int body = 0; body < NB; ++body) {
-        const bool last = body == NB - 1;
-#if TQ_P_DMA_EARLY
-        if (last && has_next) prefetch_params(tn, buf ^ 1);
-#endif
-        const float4* nxt = last ? src_next : src + (int64_t)(body + 1) * G * 64;
+      // one loop body = R rows = G groups.  EXTRA = requests other than the ring's that are younger than the requests of
+      // the first NSLOT groups of this body (the previous tile's stores in the first body, the next tile's scalars in the
+      // last one); the requests of later groups of the body were issued after those
+      auto run_body = [&](const int body, auto extra_tag) __attribute__((always_inline)) {
+        constexpr int EXTRA = decltype(extra_tag)::value;
+        tq_f2 d_lo = tq2(0.0f), d_hi = tq2(0.0f);  // the two pixel pairs of the group being consumed
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
           const float fj = (float)(body * R + rr);
@@ -1003,19 +1039,24 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(co
           }
 #pragma unroll
           for (int ip = 0; ip < P / 2; ++ip) {
-            const int pair = rr * (P / 2) + ip;
-            const int gi = pair >> 1;
-            const float4 d4 = ring[gi];
-            const tq_f2 v = ((pair & 1) ? (tq_f2){d4.z, d4.w} : (tq_f2){d4.x, d4.y}) - off0;
-            if (pair & 1) {  // last use of the group: refill it in place with the same group of the next body / tile
-              __builtin_amdgcn_sched_barrier(0);
-              ring[gi] = nxt[gi * 64];
-              __builtin_amdgcn_sched_barrier(0);
+            const int pair = rr * (P / 2) + ip;  // pair index within the body (compile-time after unrolling)
+            if ((pair & 1) == 0) {
+              const int j = body * G + (pair >> 1);  // group of the tile
+              const int slot = (slot0 + j) & (NSLOT - 1);
+              if ((pair >> 1) < NSLOT) tq_wait_vm<NSLOT - 1 + EXTRA>();
+              else tq_wait_vm<NSLOT - 1>();
+              const tq_f2* rp = reinterpret_cast<const tq_f2*>(&s_ring[slot][lane]);
+              d_lo = rp[0];
+              d_hi = rp[1];
+              asm volatile("" : "+v"(d_lo), "+v"(d_hi)::"memory");  // the read has completed: the slot is free
+              const int jn = j + NSLOT;  // the group 8 ahead in the stream refills it (next tile's first groups at the end)
+              request_group(jn < NG ? t : tnx, jn < NG ? jn : jn - NG, slot);
             }
+            const tq_f2 v = ((pair & 1) ? d_hi : d_lo) - off0;
             tq_f2 spot[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) spot[k] = agy[k] * ex[k][ip];
-            tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c);
+            tq_pixel_pair<K, P, BWD, COLACC>(A, v, b, spot, W, ip, ip == 0, c.ca, c.cb, c.s1, c.s3, c.d1, c.d2, c.d4);
           }
           if (BWD) {
 #pragma unroll
@@ -1026,20 +1067,25 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(co
             }
           }
         }
-      }
-#if !TQ_P_DMA_EARLY
-      if (has_next) prefetch_params(tn, buf ^ 1);
-#endif
+      };
+      // first body: the previous tile's result stores are younger than the requests of its groups (all of them < 8);
+      // last body: the next tile's scalar requests go first and are younger than the requests of its groups
+      run_body(0, std::integral_constant<int, NSTORE>{});
+#pragma unroll 1
+      for (int body = 1; body < NB - 1; ++body) run_body(body, std::integral_constant<int, 0>{});
+      request_params(tnx, buf ^ 1);
+      run_body(NB - 1, std::integral_constant<int, NPAR>{});
+
 #pragma unroll
-      for (int mi = 1; mi < M; ++mi) S.sS[mi] = -(A.T[mi].x + A.T[mi].y);
+      for (int mi = 1; mi < M; ++mi) S.sS[mi] = -(A.T[mi].x + A.T[mi].y);  // the assembly adds -sS; ll = sl = 0
 #pragma unroll
-      for (int k = 0; k < K; ++k) S.SN[k] = sum_ex[k] * sum_gy[k];
+      for (int k = 0; k < K; ++k) S.SN[k] = sum_ex[k] * sum_gy[k];  // sum over the tile of a separable spot
       if (BWD) {
-        S.acc_b = (A.acc_b.x + A.acc_b.y) * TQ_LN2;
+        S.acc_b = (A.acc_b.x + A.acc_b.y) * TQ_LN2;  // da was carried in units of ln 2
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           tq_f2 s0 = A.S0[k], sx = A.Sx[k], sxx = A.Sxx[k];
-          if (COLACC) {
+          if (COLACC) {  // column sums folded with the column offsets from the spot's own centre
             s0 = sx = sxx = tq2(0.0f);
             float cxe = cx[k];
             asm volatile("" : "+v"(cxe));
@@ -1059,26 +1105,34 @@ __global__ __launch_bounds__(64, (K <= 3 ? 2 : 1)) void tq_ksmogn_il2p_kernel(co
       }
     } else {
       // some unit of this tile has a small alpha = background / gain: general (scalar, exact Binet) loop on the tile in
-      // memory; the ring keeps the groups of body 0 and must be re-aimed at the next tile before it is used again
+      // memory.  The ring requests in flight are abandoned; afterwards the request pattern of a tile's end is re-issued
+      // (scalars, then the next tile's first 8 groups) so that the counts of the next tile hold.
+      tq_wait_vm<0>();
+      const float4* src = il + ((int64_t)t * NG) * 64 + lane;
       tq_il_pixel_loop<K, true, BWD, false>(S, a, src, P, npix, b, amph, nl2, cx, cy, g, rg, ln_g, W);
-      if (has_next) prefetch_params(tn, buf ^ 1);
+      tq_wait_vm<0>();
+      request_params(tnx, buf ^ 1);
 #pragma unroll
-      for (int j = 0; j < G; ++j) ring[j] = src_next[j * 64];
+      for (int j = 0; j < NSLOT; ++j) request_group(tnx, j, (slot0 + NG + j) & (NSLOT - 1));
     }
     const float S_v = sp[R_S][lane];
     const float S_lv = sp[R_S + 1][lane];
     const bool bad = sp[R_S + 2][lane] > 0.0f;
-    tq_pixel_assemble_one_offset<K, BWD>(a, S, W, b, g, rg, ln_g, (float)npix, S_v, S_lv);
-    if (live) {
+    tq_pixel_assemble_one_offset<K, BWD>(a, S, W, b, g, rg, ln_g, (float)npix, S_v, S_lv, &logit0);
+    {
       float hk[K], wk[K], cxs[K], cys[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         hk[k] = sp[R_H + k][lane];
         wk[k] = sp[R_W + k][lane];
+        // reference points of the moments: the packed loop centres y on the spot and x on the spot (column sums) or on
+        // the tile centre; the scalar fallback loop uses the tile centre for both
         cxs[k] = fastpath ? (COLACC ? 0.0f : cx[k] - 0.5f * (float)(P - 1)) : cx[k] - 0.5f * (float)(P - 1);
         cys[k] = fastpath ? 0.0f : cy[k] - 0.5f * (float)(P - 1);
       }
-      tq_pixel_store<K, true, BWD>(a, B, i, S, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
+      // (every tile has a live lane, so the NSTORE store instructions that the counts above rely on are issued whatever
+      // the tile; idle lanes of the last tile are masked out of them)
+      if (live) tq_pixel_store<K, true, BWD>(a, B, i, S, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
     }
   }
 }
@@ -1397,18 +1451,28 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
     if (ONE && (a.P == 14 || a.P == 20)) {
       const dim3 grid1((unsigned)((B + 63) / 64)), block1(64);
-      static const int persist = [] {
+      // a.pixel_mode: 1 = persistent waves (two per SIMD walk over the tiles), 0 = one wave per tile.  Which is faster
+      // depends on the box (wave-launch and memory latencies; measured 114-151 us vs 120-131 us at 400 000 units across
+      // the pool): the host times both once and says (CosmosEngine); TAPQIR_AMD_PERSIST=0/1 overrides for A/B runs
+      static const int forced = [] {
         const char* e = getenv("TAPQIR_AMD_PERSIST");
-        return e ? atoi(e) : 2;  // resident waves per SIMD that walk over the tiles; 0 = one wave per tile
+        return e ? atoi(e) : -1;
       }();
+      const int persist = forced >= 0 ? forced : a.pixel_mode;
       if (bwd && !a.gout && persist > 0 && K <= 2) {  // (K = 3 spills in this form)
-        const int ntiles = (int)((B + 63) / 64);
+        int ntiles = (int)((B + 63) / 64);
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        const int waves = cus * 4 * persist;
+        static const int waves_forced = [] {  // tests: few resident waves = many tiles per wave
+          const char* e = getenv("TAPQIR_AMD_PERSIST_WAVES");
+          return e ? atoi(e) : 0;
+        }();
+        const int waves = waves_forced > 0 ? waves_forced : cus * 4 * TQ_P_WAVES;
+        const int64_t Bn = B;
+        ntiles = (int)((Bn + 63) / 64);
         const dim3 gridp((unsigned)(ntiles < waves ? ntiles : waves));
-        if (a.P == 14) hipLaunchKernelGGL((tq_ksmogn_il2p_kernel<K, 14, true>), gridp, block1, 0, st, a, B, ntiles);
-        else hipLaunchKernelGGL((tq_ksmogn_il2p_kernel<K, 20, true>), gridp, block1, 0, st, a, B, ntiles);
+        if (a.P == 14) hipLaunchKernelGGL((tq_ksmogn_il2p_kernel<K, 14, true>), gridp, block1, 0, st, a, B, Bn, ntiles);
+        else hipLaunchKernelGGL((tq_ksmogn_il2p_kernel<K, 20, true>), gridp, block1, 0, st, a, B, Bn, ntiles);
         return launch_status("tq_ksmogn_il2p_kernel");
       }
       if (a.P == 14) {

@@ -73,6 +73,8 @@ class CosmosEngine:
         self.xy = data.xy.to(dev, f32).contiguous()
         self.is_ontarget = data.is_ontarget.to(dev, torch.uint8).contiguous()
         self.mask = data.mask.to(dev, torch.uint8).contiguous()
+        # the kernels take NULL for "no AOI is masked" (the default, dataset.py:63-65) and then skip the per-unit mask load
+        self._mask_arg = self.mask if not bool(data.mask.all()) else None
         # tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the
         # library so that any C caller gets the same layout
         self.images_il = self._interleaved_images()
@@ -115,6 +117,9 @@ class CosmosEngine:
         # sampling launch (include/tapqir_hip.h: tq_cosmos_step_overlapped); TAPQIR_AMD_OVERLAP=0 turns it off
         self.overlap_tail = os.environ.get("TAPQIR_AMD_OVERLAP", "1") != "0"
         self._tail_args = None  # arguments of the step whose tail is pending
+        # form of the backward pixel kernel for contiguous batches (include/tapqir_hip.h: pixel_mode): None = not chosen
+        # yet -> the first full-batch step times both forms on this box (autotune_pixel)
+        self.pixel_mode = None
 
     # -- the library --------------------------------------------------------------------------------
     def _open_library(self):
@@ -274,7 +279,7 @@ class CosmosEngine:
         self._keep_prev, self._keep = getattr(self, "_keep", None), (ndx, fdx)
         p = _lib.ptr
         a = _lib.CosmosArgs()
-        a.images, a.xy, a.is_ontarget, a.aoi_mask = p(self.images), p(self.xy), p(self.is_ontarget), p(self.mask)
+        a.images, a.xy, a.is_ontarget, a.aoi_mask = p(self.images), p(self.xy), p(self.is_ontarget), p(self._mask_arg)
         a.images_il = p(self.images_il)
         a.pixstats = p(self.pixstats)
         a.ndx, a.fdx = p(ndx), p(fdx)
@@ -306,6 +311,7 @@ class CosmosEngine:
         a.crosstalk = int(self.crosstalk)
         a.seed = self.seed
         a.step = self.adam_step if step is None else int(step)
+        a.pixel_mode = int(self.pixel_mode or 0)
         return a
 
     def _step_args(self, ndx, fdx):
@@ -348,6 +354,62 @@ class CosmosEngine:
     def call(self, name, args):
         _lib.check(getattr(self.lib, "tq_" + name)(C.byref(args), self._stream()), "tq_" + name)
 
+    def ksmogn_args(self, backward=True):
+        """Argument block of ``tq_ksmogn_log_prob`` for the full batch with the latents in the workspace (diagnostics,
+        bench.py's roofline leg and the autotuner)."""
+        self._workspace(self.Nt, self.F)
+        K, M = self.K, 1 << self.K
+        B = self.Nt * self.F * self.C
+        k = _lib.KsmognArgs()
+        p = _lib.ptr
+        k.images, k.images_il, k.xy, k.ndx, k.fdx = p(self.images), p(self.images_il), p(self.xy), None, None
+        k.nb_full, k.il_min_units = self.Nt, self.il_min_units
+        k.pixstats, k.stats_stride = p(self.pixstats), B
+        f = lambda row: self.lat.data_ptr() + 4 * row * B
+        k.background, k.height, k.width, k.x, k.y = f(0), f(1), f(1 + K), f(1 + 2 * K), f(1 + 3 * K)
+        k.gain = self.globals.data_ptr()
+        k.offset_samples, k.offset_logits = p(self.offset_samples), p(self.offset_logits)
+        k.gout, k.m_logit, k.aoi_mask = None, p(self._params), p(self._mask_arg)
+        g = lambda row: self.pix.data_ptr() + 4 * row * B
+        k.ll = g(0)
+        if backward:
+            k.g_background, k.g_gain = g(M), g(M + 1)
+            k.g_height, k.g_width, k.g_x, k.g_y = g(M + 2), g(M + 2 + K), g(M + 2 + 2 * K), g(M + 2 + 3 * K)
+        k.m_kstride = B
+        k.nb, k.fb, k.C, k.F, k.P, k.K, k.O = self.Nt, self.F, self.C, self.F, self.P, K, self.O
+        k.scale = 1.0
+        k.pixel_mode = int(self.pixel_mode or 0)
+        return k
+
+    def autotune_pixel(self, launches=8):
+        """Choose the form of the backward pixel kernel for this box and this dataset: the persistent form is insensitive to
+        wave-launch and memory latency, the one-wave-per-tile form is ahead where those are short (120-131 us against
+        114-151 us at 400 000 units across the boxes of one pool).  Both give the same results; a few launches of each on
+        the latents of the workspace (drawn here if the step has not run yet) decide.  Applies to K <= 2 with one offset."""
+        self.pixel_mode = 0
+        if self.crosstalk or self.K > 2 or self.O != 1 or self.P not in (14, 20) or self.Nt * self.F * self.C < self.il_min_units:
+            return 0
+        a = self.make_args()
+        self.call("cosmos_sample_globals", a)
+        self.call("cosmos_sample_locals", a)
+        times = []
+        for mode in (0, 1):
+            self.pixel_mode = mode
+            k = self.ksmogn_args(backward=True)
+            for _ in range(2):
+                _lib.check(self.lib.tq_ksmogn_log_prob(C.byref(k), self._stream()), "tq_ksmogn_log_prob")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(launches):
+                self.lib.tq_ksmogn_log_prob(C.byref(k), self._stream())
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) / launches)
+        self.pixel_mode = int(times[1] < times[0])
+        self.pixel_times_ms = times
+        self.__dict__.pop("_tmpl_key", None)  # argument templates carry the mode
+        return self.pixel_mode
+
     def step(self, ndx=None, fdx=None, allreduce=None):
         """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``).
 
@@ -356,6 +418,8 @@ class CosmosEngine:
         sites, Adam of the per-AOI and global parameters) is deferred: it runs after the NEXT step's local guide
         sampling, which needs local parameters only, so the collective's latency hides behind that kernel.  ``join()``
         (called by every read-out) completes a deferred tail."""
+        if self.pixel_mode is None and ndx is None and fdx is None and self.pipelined_tail:
+            self.autotune_pixel()
         a = self._step_args(ndx, fdx)
         minibatch = bool(a.zero_grad)
         # Adam on the local block is fused into the unit kernel: full batches, and minibatches with the lazy clock

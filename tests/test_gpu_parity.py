@@ -16,12 +16,13 @@ from test_hostcheck_parity import CASES
 pytestmark = pytest.mark.gpu
 
 
-def run_case_gpu(dkw, K, ndx, fdx, perturb=0.3, il_min_units=None):
+def run_case_gpu(dkw, K, ndx, fdx, perturb=0.3, il_min_units=None, pixel_mode=None):
     d = make_dataset(K=K, **dkw)
     o = make_oracle(d, K, perturb=perturb)
     eng = CosmosEngine(d, K=K, device="cuda:0")
     if il_min_units is not None:
         eng.il_min_units = il_min_units
+    eng.pixel_mode = pixel_mode  # form of the backward pixel kernel on the interleaved layout (None: one wave per tile)
     oracle_to_engine(o, eng)
     nd = torch.arange(d.images.shape[0]) if ndx is None else torch.tensor(ndx)
     fd = torch.arange(d.images.shape[1]) if fdx is None else torch.tensor(fdx)
@@ -179,9 +180,10 @@ IL_CASES = [  # contiguous batches through the lane-per-unit kernel on the inter
 ]
 
 
+@pytest.mark.parametrize("pixel_mode", [0, 1], ids=["wave_per_tile", "persistent"])
 @pytest.mark.parametrize("name,dkw,K", IL_CASES, ids=[c[0] for c in IL_CASES])
-def test_interleaved_kernel_matches_oracle(name, dkw, K):
-    o, eng, elbo_o, g_o = run_case_gpu(dkw, K, None, None, il_min_units=1)
+def test_interleaved_kernel_matches_oracle(name, dkw, K, pixel_mode):
+    o, eng, elbo_o, g_o = run_case_gpu(dkw, K, None, None, il_min_units=1, pixel_mode=pixel_mode)
     assert eng.images_il is not None
     elbo_k = float(eng.elbo_out[0])
     assert abs(elbo_k - elbo_o) <= 1e-5 * abs(elbo_o), (elbo_k, elbo_o)
@@ -191,14 +193,40 @@ def test_interleaved_kernel_matches_oracle(name, dkw, K):
         assert rel_err(got, ref) < 1e-4, (n, rel_err(got, ref))
 
 
-def test_interleaved_and_tiled_kernels_agree():
-    """Same inputs through both pixel kernels (forward + backward outputs)."""
-    outs = []
-    for il in (1, 1 << 30):
-        _, eng, _, _ = run_case_gpu(dict(N=5, F=29), 2, None, None, il_min_units=il)
-        outs.append(eng.pix.cpu().double().clone())
-    scale = outs[1].abs().max()
-    assert (outs[0] - outs[1]).abs().max() <= 2e-5 * scale
+@pytest.mark.parametrize("pixel_mode", [0, 1], ids=["wave_per_tile", "persistent"])
+def test_interleaved_and_tiled_kernels_agree(pixel_mode):
+    """Same inputs through both pixel kernels (forward + backward outputs); 145 and 1305 units: ragged last tiles."""
+    for dkw in (dict(N=5, F=29), dict(N=9, F=145)):
+        outs = []
+        for il in (1, 1 << 30):
+            _, eng, _, _ = run_case_gpu(dkw, 2, None, None, il_min_units=il, pixel_mode=pixel_mode)
+            outs.append(eng.pix.cpu().double().clone())
+        scale = outs[1].abs().max()
+        assert (outs[0] - outs[1]).abs().max() <= 2e-5 * scale
+
+
+def test_persistent_kernel_with_few_resident_waves(monkeypatch):
+    """The persistent form with MANY tiles per wave (the ring / slab hand-over between tiles, the dummy requests of a
+    wave's last tile): 21 tiles, wave count forced down through the kernel's A/B switch."""
+    import subprocess
+    import sys
+    import os
+
+    code = (
+        "import sys, os, torch\n"
+        "sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))\n"
+        "from test_gpu_parity import run_case_gpu\n"
+        "outs = []\n"
+        "for il, mode in ((1, 1), (1 << 30, 0)):\n"
+        "    _, eng, _, _ = run_case_gpu(dict(N=9, F=145), 2, None, None, il_min_units=il, pixel_mode=mode)\n"
+        "    outs.append(eng.pix.cpu().double().clone())\n"
+        "err = float((outs[0] - outs[1]).abs().max() / outs[1].abs().max())\n"
+        "print('ERR', err)\n"
+        "assert err <= 2e-5\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAPQIR_AMD_PERSIST_WAVES="4")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_interleave_layout():

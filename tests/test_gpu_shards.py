@@ -104,9 +104,13 @@ def _oracle_for_units(s, eng, nd, fd):
     return o, base, ar_n, ar_f
 
 
-def test_sampled_units_match_the_oracle(shard):
+@pytest.mark.parametrize("pixel_mode", [0, 1], ids=["wave_per_tile", "persistent"])
+def test_sampled_units_match_the_oracle(shard, pixel_mode):
     s = shard
+    if pixel_mode and (s.xt or s.K > 2):
+        pytest.skip("the persistent form covers cosmos K <= 2")
     eng = s.engine()
+    eng.pixel_mode = pixel_mode
     s.perturb(eng)
     _stages(eng)
     K, M, C = s.K, 1 << s.K, s.C
@@ -174,12 +178,16 @@ def test_elbo_is_additive_over_aoi_shards(shard):
     assert abs(float(total[2]) - float(gs_full[2])) <= 1e-7 * abs(float(gs_full[2]))
 
 
-def test_pixel_kernels_agree(shard):
+@pytest.mark.parametrize("pixel_mode", [0, 1], ids=["wave_per_tile", "persistent"])
+def test_pixel_kernels_agree(shard, pixel_mode):
     s = shard
+    if pixel_mode and (s.xt or s.K > 2):
+        pytest.skip("the persistent form covers cosmos K <= 2")
     outs = []
     for il in (1, 1 << 30):
         eng = s.engine()
         eng.il_min_units = il
+        eng.pixel_mode = pixel_mode
         _stages(eng)
         outs.append(eng.pix.view(-1, s.N * s.F * s.C).clone())
         del eng
