@@ -248,7 +248,17 @@ typedef struct {
   int32_t* last_step;          /* [Nt*F*C] Adam step at which the local parameters of a unit were last updated, or NULL */
   double beta1_d, beta2_d;     /* the Adam betas in double: 1 - beta^s of the replayed steps is formed like the host's */
   int32_t pixel_mode;          /* passed on to tq_ksmogn_args.pixel_mode */
+  int32_t tail_kind;           /* how the pending tail of THIS step finds its partial sums: TQ_TAIL_AUTO (what tq_cosmos_step /
+                                  _step_overlapped / _elbo_grads wrote) or TQ_TAIL_ROWS16 (the step ran as
+                                  tq_cosmos_minibatch_step); the host sets it on the struct it later passes as `prev` / to
+                                  tq_cosmos_tail */
+  int32_t* sync;               /* [4] zero-initialised words of tq_cosmos_minibatch_step (workgroup tickets, flag), or NULL */
+  int32_t sync_value;          /* value the flag takes in this launch: any value different from the previous launch's on the
+                                  same `sync` words (a launch counter of the host) */
 } tq_cosmos_args;
+
+#define TQ_TAIL_AUTO 0
+#define TQ_TAIL_ROWS16 1
 
 int64_t tq_globals_size(void);
 int64_t tq_gbase_size(void);
@@ -290,6 +300,14 @@ int tq_cosmos_adam_catchup(const tq_cosmos_args* a, int32_t all_units, void* str
  * reading elbo_out / the per-AOI and global parameters.  prev == NULL: nothing pending (first step). */
 int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
 int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
+/* Minibatch steps (the reference's default operating point is 10 AOIs x 512 frames = 5120 units, main.py:1428-1431) in
+ * ONE launch: every workgroup takes 16 units through lazy-Adam catch-up, guide-site draws, likelihood and per-unit terms +
+ * Adam; the first workgroup to start also runs the pending tail of `prev` (or nothing) and the global draws of `a`, which
+ * the others wait for before their likelihood phase.  Same arithmetic, same RNG streams and same results as
+ * tq_cosmos_adam_catchup + tq_cosmos_step_overlapped; the tail of `a` stays pending: pass `a` (with tail_kind =
+ * TQ_TAIL_ROWS16) as `prev` of the next step of either kind or to tq_cosmos_tail.  cosmos model, fuse_adam,
+ * fb * C >= 16; `sync` must point to 4 zero-initialised int32. */
+int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
 
 /* AOI-sharded runs: everything that follows the all-reduce of gsum (tq_cosmos_globals_grad + tq_cosmos_adam) in one
  * single-workgroup launch, plus -- if `next` is given (full-batch steps) -- the global draws of the next step

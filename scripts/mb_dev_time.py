@@ -1,0 +1,30 @@
+"""Device time per minibatch step with device-resident indices."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tapqir_amd.models.cosmos import initial_values
+from tapqir_amd.models.engine import CosmosEngine
+from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+dev = torch.device("cuda", 0)
+class _M: K, device = 2, dev
+data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
+eng = CosmosEngine(data, K=2, device=dev, seed=7)
+eng.layout.set_constrained(eng.params, initial_values(eng, data))
+g = torch.Generator().manual_seed(0)
+nb, fb = int(os.environ.get("NB", 10)), int(os.environ.get("FB", 512))
+didx = [(torch.randperm(400, generator=g)[:nb].to(dev, torch.int32), torch.randperm(1000, generator=g)[:fb].to(dev, torch.int32)) for _ in range(200)]
+for nd, fd in didx[:20]:
+    eng.step(nd, fd)
+torch.cuda.synchronize()
+for rep in range(3):
+    t0 = time.perf_counter()
+    for nd, fd in didx:
+        eng.step(nd, fd)
+    torch.cuda.synchronize()
+    print(f"{nb}x{fb}: {1e6 * (time.perf_counter() - t0) / len(didx):.1f} us/step", flush=True)
+if os.environ.get("STAMPS"):
+    torch.cuda.synchronize()
+    st = eng._sync[4:20].cpu().view(torch.int64)
+    print("ticket barrier %.1f us, to phase-1 start %.1f us" % ((int(st[6]) - int(st[0])) / 100.0, (int(st[7]) - int(st[0])) / 100.0))
+    d = [(int(st[i + 1]) - int(st[i])) / 100.0 for i in range(5)]
+    print("stamps (us): catchup %.1f  sites %.1f  wait %.1f  pixel %.1f  unit %.1f  total %.1f" % (*d, (int(st[5]) - int(st[0])) / 100.0))

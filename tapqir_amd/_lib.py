@@ -63,7 +63,7 @@ class CosmosArgs(C.Structure):
         ("zero_grad", C.c_int32), ("fuse_adam", C.c_int32), ("crosstalk", C.c_int32),
         ("seed", C.c_uint64), ("step", C.c_uint32),
         ("last_step", C.c_void_p), ("beta1_d", C.c_double), ("beta2_d", C.c_double),
-        ("pixel_mode", C.c_int32),
+        ("pixel_mode", C.c_int32), ("tail_kind", C.c_int32), ("sync", C.c_void_p), ("sync_value", C.c_int32),
     ]
 
 
@@ -138,7 +138,7 @@ EXPORTS = [
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
-    "tq_cosmos_blk_floats",
+    "tq_cosmos_blk_floats", "tq_cosmos_minibatch_step",
     "tq_cosmos_probs", "tq_glimpse_extract", "tq_ksmogn_rsample", "tq_snr_chi2",
 ]
 
@@ -190,7 +190,7 @@ def load():
         fn.restype = C.c_int
     lib.tq_cosmos_blk_floats.argtypes = [C.c_int32] * 4 + [C.c_int64]
     lib.tq_cosmos_blk_floats.restype = C.c_int64
-    for name in ("tq_cosmos_step_overlapped", "tq_cosmos_tail_reduced"):
+    for name in ("tq_cosmos_step_overlapped", "tq_cosmos_tail_reduced", "tq_cosmos_minibatch_step"):
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int

@@ -226,6 +226,8 @@ __global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_ar
 #define TQ_ROWS_GCOL (2 * TQ_ROWS_AOICOL)
 #define TQ_ROWS_MAXCOL (TQ_ROWS_GCOL + TQ_MAX_NGSUM)
 
+#include "tq_ksmogn_dev.h"
+
 // (host) does this step use the rows layout?  TAPQIR_AMD_ROWS=0 keeps the flat layout + tq_aoi_kernel (A/B timing)
 static bool tq_rows_layout(const tq_cosmos_args& a) {
   static const bool enabled = [] {
@@ -233,6 +235,12 @@ static bool tq_rows_layout(const tq_cosmos_args& a) {
     return !(e && e[0] == '0');
   }();
   return enabled && a.fuse_adam && !a.ndx && !a.fdx && a.nb == a.Nt && a.fb == a.F && a.F * a.C >= TQ_UNIT_BLOCK;
+}
+
+// has_prev code of a pending step for the kernels that run its tail
+static int tq_prev_code(const tq_cosmos_args& prev) {
+  if (prev.tail_kind == TQ_TAIL_ROWS16) return 4;
+  return tq_rows_layout(prev) ? 3 : 1;
 }
 
 template <int K>
@@ -289,24 +297,26 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
 
 // Tail of a step whose per-unit kernel wrote such rows (ONE workgroup of 256 threads): per-AOI sites from the rows that
 // overlap the AOI, cross-unit sums in fp64, global sites and the total ELBO.
+// UPR = units per row: TQ_UNIT_BLOCK (tq_unit_rows_kernel) or 16 (the single-launch minibatch step)
+template <int UPR>
 __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
   const int64_t B = tq_batch_units(a);
-  const int64_t nrows = (B + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK;
-  const uint32_t FC = (uint32_t)(a.F * a.C);
+  const int64_t nrows = (B + UPR - 1) / UPR;
+  const uint32_t FC = (uint32_t)(a.fb * a.C);  // units of one AOI of the batch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double acc[TQ_MAX_NGSUM];
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
   // per-AOI sites: frame sums = sums over the rows that overlap the AOI; prior terms; gradient of the AOI parameters
-  const int nac = a.Nt * a.C;
+  const int nac = a.nb * a.C;
   for (int ac = threadIdx.x; ac < nac; ac += 256) {
-    const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;
+    const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;  // position of the AOI in the batch
     const int c = ac - (int)ai * a.C;
-    const uint32_t r_lo = (ai * FC) / TQ_UNIT_BLOCK, r_hi = ((ai + 1) * FC - 1) / TQ_UNIT_BLOCK;
+    const uint32_t r_lo = (ai * FC) / UPR, r_hi = ((ai + 1) * FC - 1) / UPR;
     float s1 = 0.0f, s2 = 0.0f;
     for (uint32_t r = r_lo; r <= r_hi; ++r) {
-      const int slot = (r * TQ_UNIT_BLOCK) / FC == ai ? 0 : 1;
+      const int slot = (r * UPR) / FC == ai ? 0 : 1;
       const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
       s1 += row[0];
       s2 += row[1];
@@ -334,10 +344,11 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   tq_globals_from_gsum_body(a, s_e);
 }
 
-__global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_cosmos_args a) {
+__global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_cosmos_args a, const int upr) {
   __shared__ double s_w[4][TQ_MAX_NGSUM];
   __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
-  tq_rows_reduce_globals_body(a, s_w, s_e);
+  if (upr == 16) tq_rows_reduce_globals_body<16>(a, s_w, s_e);
+  else tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(a, s_w, s_e);
 }
 
 // Full-batch pipeline (tq_cosmos_step_overlapped): the local guide sampling of step t, with ONE extra workgroup (block (0, 0),
@@ -347,15 +358,16 @@ __global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_co
 // step t-1), so the ~35 us latency chain of the tail hides behind the ~14 000 sampling workgroups of the same launch.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tq_sample_locals_tail_kernel(
     const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B, const int site_begin) {
-  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 = the same from AOI-aligned
-  // rows, per-AOI sites included), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
+  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 / 4 = the same from rows of 256 /
+  // 16 units with the per-AOI sites folded in), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
   if (blockIdx.y == 0) {
     if (blockIdx.x != 0) return;
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
-      if (has_prev == 3) tq_rows_reduce_globals_body(prev, s_w, s_e);
+      if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
+      else if (has_prev == 4) tq_rows_reduce_globals_body<16>(prev, s_w, s_e);
       else if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
       else tq_globals_from_gsum_body(prev, s_e);
       __syncthreads();
@@ -371,6 +383,184 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y - 1, i);
+}
+
+
+// =============================================================================================================
+// Single-launch minibatch step (tq_cosmos_minibatch_step).
+//
+// The reference's default operating point (10 AOIs x 512 frames, main.py:1428-1431) is 5120 units: 80 waves of work for
+// a chip with 4096 wave slots.  As five launches (lazy-Adam catch-up, site draws + previous tail, likelihood, per-unit,
+// per-AOI) a step costs five launch latencies on the device (70 us) and about as much on the host, which becomes the
+// bottleneck.  Here ONE launch runs a step; a workgroup owns 16 units through all phases:
+//   ticket 0 only : tail of the PREVIOUS step (cross-unit sums, per-AOI sites, global sites, ELBO, Adam of the per-AOI /
+//                   global parameters), then the global draws of this step; publishes a flag (device-scope release);
+//   phase 1       : lazy-Adam catch-up of the 16 units' local parameters, then their 9 x 16 guide-site draws;
+//   (wait)        : one lane polls the flag (the likelihood needs this step's gain, the per-unit terms its tables);
+//   phase 2       : the 16-lanes-per-unit likelihood routine of tq_ksmogn_kernel (tq_ksmogn_tile16);
+//   phase 3       : per-unit ELBO terms, gradients and Adam (one lane per unit), row of partial sums with the per-AOI
+//                   frame sums folded in (rows of 16 units, tq_rows_reduce_globals_body<16>).
+// Phases hand data over through the step workspace in global memory; a workgroup lives on one CU, whose L1 its waves
+// share, so a workgroup barrier orders those accesses.  The ticket-0 workgroup never waits for another one, so the
+// waiting workgroups cannot deadlock whatever the dispatch order.  The tail of THIS step runs in the next launch (or in
+// tq_cosmos_tail).
+// =============================================================================================================
+template <int K, bool ONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void tq_minibatch_kernel(
+    const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const tq_ksmogn_args k, const int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_ticket, s_ok;
+  __shared__ float s_part[4][TQ_ROWS_MAXCOL];
+  const int tid = threadIdx.x;
+#ifdef TQ_MB_STAMPS
+#define TQ_STAMP(n) if (tid == 0 && blockIdx.x == TQ_MB_STAMPS) ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TQ_STAMP(n)
+#endif
+  TQ_STAMP(0)
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(&a.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  TQ_STAMP(6)
+  const int ticket = s_ticket;
+  const int flag_value = a.sync_value;
+  if (ticket == 0) {  // the extra workgroup of the grid: owns no units
+    __shared__ double s_w[4][TQ_MAX_NGSUM];
+    __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+    if (has_prev) {
+      const int64_t Bp = tq_batch_units(prev);
+      if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
+      else if (has_prev == 4) tq_rows_reduce_globals_body<16>(prev, s_w, s_e);
+      else tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
+      __syncthreads();
+      const int64_t total = tq_num_params(prev);
+      for (int64_t j = tq_aoi_base(prev) + tid; j < total; j += 256) tq_body_adam(prev, j);
+      __threadfence_block();
+      __syncthreads();
+    }
+    const int ns = tq_num_gsites(a);
+    if ((tid & 63) == 0)
+      for (int s = tid >> 6; s < ns; s += 4) tq_body_sample_globals(a, s);
+    // publish: every storing wave drains, workgroup barrier, one lane releases at device scope and sets the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&a.sync[1], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // re-arm the ticket counter when every workgroup has taken its ticket
+    if (tid == 0) {
+      const int done = __hip_atomic_fetch_add(&a.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == (int)gridDim.x - 1) {
+        __hip_atomic_store(&a.sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.sync[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  // ---- phase 1: catch-up + site draws of this workgroup's 16 units (work index = ticket - 1) ----
+  const int64_t wblk = ticket - 1;
+  const int64_t u0 = wblk * TQ_UNITS_PER_BLOCK;
+  constexpr int NL = TQ_NLOCAL(K), NS = 1 + 4 * K;
+  TQ_STAMP(7)
+  if (a.last_step) {
+    for (int e = tid; e < NL * TQ_UNITS_PER_BLOCK; e += 256) {
+      const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
+      if (i < B) {
+        const int64_t u = tq_decode_unit(a, i).u;
+        tq_adam_replay(a, (int64_t)(e >> 4) * tq_num_units(a) + u, a.last_step[u] + 1, (int)a.step);
+      }
+    }
+    __syncthreads();
+  }
+  TQ_STAMP(1)
+  for (int e = tid; e < NS * TQ_UNITS_PER_BLOCK; e += 256) {
+    const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
+    if (i < B) tq_body_site(a, e >> 4, i);
+  }
+  __syncthreads();
+  TQ_STAMP(2)
+  // ---- wait for the global draws of this step (bounded: ~2 s of the 100 MHz wall clock) ----
+  {
+    if (tid == 0) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      int ok = 1;
+      while (__hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flag_value) {
+        __builtin_amdgcn_s_sleep(16);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+          ok = 0;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_ok = ok;
+    }
+  }
+  __syncthreads();
+  if (!s_ok) {  // never observed: leave a visible trace (NaN loss) instead of reading half-written tables
+    if (tid == 0 && wblk == 0) a.elbo_out[0] = __builtin_nan("");
+    return;
+  }
+  TQ_STAMP(3)
+  // ---- phase 2: likelihood of the 16 units (reads the draws of phase 1 and the gain) ----
+  tq_ksmogn_tile16<K, ONE, true>(k, B, wblk, smem);
+  __syncthreads();
+  TQ_STAMP(4)
+  // ---- phase 3: per-unit terms + Adam, one lane per unit; row of partial sums ----
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  float part[TQ_MAX_NGSUM], aoi[TQ_ROWS_GCOL];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < TQ_ROWS_GCOL; ++j) aoi[j] = 0.0f;
+  const int64_t i = u0 + (tid >> 4);
+  if ((tid & 15) == 0 && i < B) {
+    float aoi2[2];
+    tq_body_unit<K>(a, i, part, aoi2);
+    const uint32_t FC = (uint32_t)(a.fb * a.C);
+    const int c = (int)((uint32_t)i % (uint32_t)a.C);
+    const int slot = (uint32_t)i / FC == (uint32_t)u0 / FC ? 0 : 1;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+      for (int q = 0; q < TQ_MAXQ; ++q) {
+        const bool mine = sl == slot && q == c;
+        aoi[sl * TQ_ROWS_AOICOL + 2 * q] = mine ? aoi2[0] : 0.0f;
+        aoi[sl * TQ_ROWS_AOICOL + 2 * q + 1] = mine ? aoi2[1] : 0.0f;
+      }
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < TQ_ROWS_GCOL; ++j) {
+    if ((j % TQ_ROWS_AOICOL) < 2 * a.C) {
+      const float sum = tq_wave_sum(aoi[j]);
+      if (lane == 0) s_part[wave][j] = sum;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const float sum = tq_wave_sum(part[j]);
+      if (lane == 0) s_part[wave][TQ_ROWS_GCOL + j] = sum;
+    }
+  }
+  __syncthreads();
+  if (tid < ncol) {
+    const bool used = tid >= TQ_ROWS_GCOL || (tid % TQ_ROWS_AOICOL) < 2 * a.C;
+    const float sum = used ? (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]) : 0.0f;
+    a.blk_part[wblk * ncol + tid] = sum;
+  }
+  TQ_STAMP(5)
+  // the last workgroup to get here re-arms the ticket counter for the next launch (the flag holds the step number)
+  if (tid == 0) {
+    const int done = __hip_atomic_fetch_add(&a.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {
+      __hip_atomic_store(&a.sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.sync[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 
@@ -436,8 +626,8 @@ extern "C" int tq_cosmos_sample_locals(const tq_cosmos_args* a, void* stream) {
   return check_launch("tq_sample_locals_kernel");
 }
 
-// pixel kernel of a step: fused render + log-likelihood + pathwise gradients, Dice weights from m_probs
-static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
+// argument block of the likelihood kernel of a cosmos step
+static tq_ksmogn_args cosmos_ksmogn_args(const tq_cosmos_args* a) {
   const int K = a->K, M = 1 << K;
   const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
   tq_ksmogn_args k = {};
@@ -445,7 +635,7 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   k.nb_full = a->Nt;
   k.pixstats = a->pixstats;
   k.stats_stride = U;
-  k.il_min_units = a->il_min_units;  // below ~1 wave per SIMD the 16-lanes-per-unit kernel has more parallelism
+  k.il_min_units = a->il_min_units;
   k.pixel_mode = a->pixel_mode;
   k.background = a->lat;
   k.height = a->lat + (int64_t)1 * B;
@@ -455,7 +645,7 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   k.gain = &((const TqGlobals*)a->globals)->gain;
   k.offset_samples = a->offset_samples; k.offset_logits = a->offset_logits;
   k.gout = nullptr;
-  k.m_logit = a->params;  // rows TQ_ROW(TQ_P_MPROBS, k, K) = k
+  k.m_logit = a->params;
   k.m_kstride = U;
   k.aoi_mask = a->aoi_mask;
   k.ll = a->pix;
@@ -467,6 +657,14 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   k.g_y = a->pix + (int64_t)(M + 2 + 3 * K) * B;
   k.nb = a->nb; k.fb = a->fb; k.C = a->C; k.F = a->F; k.P = a->P; k.K = K; k.O = a->O;
   k.scale = a->scale;
+  return k;
+}
+
+// pixel kernel of a step: fused render + log-likelihood + pathwise gradients, Dice weights from m_probs
+static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
+  const int K = a->K, M = 1 << K;
+  const int64_t B = tq_batch_units(*a), U = tq_num_units(*a);
+  tq_ksmogn_args k = cosmos_ksmogn_args(a);
   if (a->crosstalk) {
     // one data site per AOI-frame, all dyes in every channel: per-dye marginal likelihoods go where the cosmos
     // per-unit routine expects ll, two more row groups follow the cosmos block of pix
@@ -585,8 +783,8 @@ static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
     return TQ_ERR_ARG;
   }
   // no all-reduce on this path: sums, (per-AOI sites,) global sites and the total ELBO finish in one launch
-  if (tq_rows_layout(*a)) {
-    hipLaunchKernelGGL(tq_rows_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a);
+  if (a->tail_kind == TQ_TAIL_ROWS16 || tq_rows_layout(*a)) {
+    hipLaunchKernelGGL(tq_rows_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a, a->tail_kind == TQ_TAIL_ROWS16 ? 16 : TQ_UNIT_BLOCK);
     return check_launch("tq_rows_reduce_globals_kernel");
   }
   const int64_t B = tq_batch_units(*a);
@@ -641,16 +839,56 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
   }
   const int64_t B = tq_batch_units(*a);
   hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(2 + 4 * a->K)), dim3(256), 0,
-                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? (tq_rows_layout(*prev) ? 3 : 1) : 0, B, 0);
+                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? tq_prev_code(*prev) : 0, B, 0);
   if (int rc = check_launch("tq_sample_locals_tail_kernel")) return rc;
   return elbo_grads_impl(a, stream, false, tq_rows_layout(*a));
 }
 
 
 extern "C" int64_t tq_cosmos_blk_floats(int32_t Nt, int32_t F, int32_t C, int32_t crosstalk, int64_t B) {
-  const int64_t full = tq_cosmos_nblk((int64_t)Nt * F * C) * (TQ_ROWS_GCOL + TQ_NGSUM_X(C, crosstalk));  // full-batch rows
+  const int64_t ncol = TQ_ROWS_GCOL + TQ_NGSUM_X(C, crosstalk);
+  const int64_t full = tq_cosmos_nblk((int64_t)Nt * F * C) * ncol;                           // full-batch rows of 256 units
+  const int64_t mini = ((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) * ncol;          // single-launch minibatch step: rows of 16
   const int64_t flat = tq_cosmos_nblk(B) * TQ_NGSUM_X(C, crosstalk);
-  return full > flat ? full : flat;
+  return full > mini ? (full > flat ? full : flat) : (mini > flat ? mini : flat);
+}
+
+
+extern "C" int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream) {
+  if (int rc = check_args(a, "minibatch_step")) return rc;
+  if (prev)
+    if (int rc = check_args(prev, "minibatch_step (prev)")) return rc;
+  if (a->crosstalk || !a->fuse_adam || (prev && !prev->fuse_adam) || (int64_t)a->fb * a->C < TQ_UNITS_PER_BLOCK) {
+    tq_set_error("tq_cosmos_minibatch_step: cosmos steps with fuse_adam and at least 16 units per AOI only");
+    return TQ_ERR_ARG;
+  }
+  if (!a->images || !a->xy || !a->is_ontarget || !a->offset_samples || !a->offset_logits || !a->lat || !a->site || !a->pix ||
+      !a->blk_part || !a->gsum || !a->elbo_out || !a->exp_avg || !a->exp_avg_sq || !a->grad || !a->sync ||
+      (prev && (!prev->grad || !prev->gsum || !prev->elbo_out || !prev->exp_avg || !prev->exp_avg_sq || !prev->blk_part ||
+                (tq_prev_code(*prev) == 1 && !prev->aoi_part)))) {
+    tq_set_error("tq_cosmos_minibatch_step: NULL required pointer");
+    return TQ_ERR_ARG;
+  }
+  const int64_t B = tq_batch_units(*a);
+  const tq_ksmogn_args k = cosmos_ksmogn_args(a);
+  const bool one = a->O == 1 && a->pixstats;
+  // one workgroup per 16 units + the one that runs the tail and the global draws
+  const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) + 1), block(256);
+  const size_t lds = sizeof(float) * tq_tile16_lds_floats(a->P, a->K);
+  const int code = prev ? tq_prev_code(*prev) : 0;
+  const tq_cosmos_args& pv = prev ? *prev : *a;
+  hipStream_t st = (hipStream_t)stream;
+#define TQ_MB_LAUNCH(KK)                                                                                         \
+  if (one) hipLaunchKernelGGL((tq_minibatch_kernel<KK, true>), grid, block, lds, st, *a, pv, code, k, B);       \
+  else hipLaunchKernelGGL((tq_minibatch_kernel<KK, false>), grid, block, lds, st, *a, pv, code, k, B);
+  switch (a->K) {
+    case 1: TQ_MB_LAUNCH(1) break;
+    case 2: TQ_MB_LAUNCH(2) break;
+    case 3: TQ_MB_LAUNCH(3) break;
+    default: TQ_MB_LAUNCH(4) break;
+  }
+#undef TQ_MB_LAUNCH
+  return check_launch("tq_minibatch_kernel");
 }
 
 // AOI-sharded pipeline: the local sites [site_begin, site_begin + site_count) of `a`; with `prev` (whose gsum the caller

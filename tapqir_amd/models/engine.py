@@ -120,6 +120,11 @@ class CosmosEngine:
         # form of the backward pixel kernel for contiguous batches (include/tapqir_hip.h: pixel_mode): None = not chosen
         # yet -> the first full-batch step times both forms on this box (autotune_pixel)
         self.pixel_mode = None
+        # minibatch steps with the lazy Adam clock run as ONE launch (include/tapqir_hip.h: tq_cosmos_minibatch_step);
+        # TAPQIR_AMD_MB_FUSED=0 keeps the five-launch sequence
+        self.fused_minibatch = self.pipelined_tail and os.environ.get("TAPQIR_AMD_MB_FUSED", "1") != "0"
+        self._sync = torch.zeros(32, dtype=torch.int32, device=dev)  # 4 words + room for the diagnostic stamps of a TQ_MB_STAMPS build
+        self._sync_value = 0
 
     # -- the library --------------------------------------------------------------------------------
     def _open_library(self):
@@ -240,27 +245,46 @@ class CosmosEngine:
         self._ws_key = key
 
     def _index_to_device(self, idx, which):
-        """Subsample indices as a device int32 tensor.  Host tensors go through a small ring of pinned staging buffers
-        and an asynchronous copy: a pageable copy would block the host until the stream has drained, once per step."""
-        if idx.device.type == "cuda" or self.device.type != "cuda":
-            return idx.to(self.device, torch.int32).contiguous()
-        ring = self.__dict__.setdefault("_pin_ring", {})
-        if which not in ring:
-            n = max(self.Nt, self.F)
-            ring[which] = [[torch.empty(n, dtype=torch.int32).pin_memory(), torch.cuda.Event(), False] for _ in range(8)]
-        slots = ring[which]
-        k = self.__dict__.setdefault("_pin_count", [0, 0])
-        slot = slots[k[which] % len(slots)]
-        k[which] += 1
-        buf, ev, used = slot
+        """One subsample index vector as a device int32 tensor (see _indices_to_device for the step's fast path)."""
+        return idx.to(self.device, torch.int32).contiguous()
+
+    def _indices_to_device(self, ndx, fdx):
+        """Subsample indices of a step as device int32 tensors.  Host tensors (what ``torch.randperm`` gives the caller
+        every step) take ONE asynchronous copy: both vectors are written, converted to int32, into a pinned staging
+        slot and copied into a persistent device slot of the same ring -- no allocation, no pageable copy (which would
+        block the host until the stream has drained) and a few microseconds of host time instead of ~40 per vector,
+        which made the host the bottleneck of the default 10 x 512 minibatch step."""
+        host = [t is not None and t.device.type == "cpu" for t in (ndx, fdx)]
+        if self.device.type != "cuda" or not any(host):
+            return (None if ndx is None else self._index_to_device(ndx, 0)), (None if fdx is None else self._index_to_device(fdx, 1))
+        ring = self.__dict__.get("_idx_ring")
+        if ring is None:
+            n = self.Nt + self.F
+            ring = []
+            for _ in range(16):
+                pin = torch.empty(n, dtype=torch.int32).pin_memory()
+                ring.append([pin, pin.numpy(), torch.empty(n, dtype=torch.int32, device=self.device), torch.cuda.Event(), False])
+            self._idx_ring, self._idx_count = ring, 0
+        slot = ring[self._idx_count % len(ring)]
+        self._idx_count += 1
+        pin, pin_np, dev, ev, used = slot
         if used:
-            ev.synchronize()  # the copy that last read this buffer (8 steps ago) has completed
-        n = idx.numel()
-        buf[:n].copy_(idx.reshape(-1))
-        out = buf[:n].to(self.device, non_blocking=True)
+            ev.synchronize()  # the copy that last read this staging slot (16 steps ago) has completed
+        pos, out = 0, []
+        for t, h in zip((ndx, fdx), host):
+            if t is None:
+                out.append(None)
+            elif h:
+                k = t.numel()
+                pin_np[pos:pos + k] = t.numpy().reshape(-1)  # int64 -> int32
+                out.append((pos, k))
+                pos += k
+            else:
+                out.append(t.to(self.device, torch.int32).contiguous())
+        dev[:pos].copy_(pin[:pos], non_blocking=True)
         ev.record()  # on the current stream
-        slot[2] = True
-        return out
+        slot[4] = True
+        return tuple(dev[o[0]:o[0] + o[1]] if isinstance(o, tuple) else o for o in out)
 
     def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None,
                   _for_step=False):
@@ -271,10 +295,7 @@ class CosmosEngine:
         nb = self.Nt if ndx is None else int(ndx.numel())
         fb = self.F if fdx is None else int(fdx.numel())
         self._workspace(nb, fb)
-        if ndx is not None:
-            ndx = self._index_to_device(ndx, 0)
-        if fdx is not None:
-            fdx = self._index_to_device(fdx, 1)
+        ndx, fdx = self._indices_to_device(ndx, fdx)
         # keep the index tensors alive while kernels run (the previous step's too: its tail may still be pending)
         self._keep_prev, self._keep = getattr(self, "_keep", None), (ndx, fdx)
         p = _lib.ptr
@@ -312,6 +333,7 @@ class CosmosEngine:
         a.seed = self.seed
         a.step = self.adam_step if step is None else int(step)
         a.pixel_mode = int(self.pixel_mode or 0)
+        a.sync, a.tail_kind = p(self._sync), 0
         return a
 
     def _step_args(self, ndx, fdx):
@@ -327,10 +349,7 @@ class CosmosEngine:
                                                                               self.seed, id(self.priors), self._ws_key)
             return a
         a = _lib.CosmosArgs.from_buffer_copy(self._tmpl)
-        if ndx is not None:
-            ndx = self._index_to_device(ndx, 0)
-        if fdx is not None:
-            fdx = self._index_to_device(fdx, 1)
+        ndx, fdx = self._indices_to_device(ndx, fdx)
         self._keep_prev, self._keep = self._keep, (ndx, fdx)
         a.ndx, a.fdx = _lib.ptr(ndx), _lib.ptr(fdx)
         t = self.adam_step + 1
@@ -424,17 +443,30 @@ class CosmosEngine:
         minibatch = bool(a.zero_grad)
         # Adam on the local block is fused into the unit kernel: full batches, and minibatches with the lazy clock
         a.fuse_adam = int(not minibatch or self.lazy_adam)
+        one_launch = (minibatch and self.lazy_adam and self.fused_minibatch and allreduce is None and not self.crosstalk
+                      and a.fb * self.C >= 16)
         if minibatch and self.lazy_adam:
             if not self._stale:
                 self._last_step.fill_(self.adam_step)  # every unit is current: start the clock here
                 self._stale = True
-            self._adam_catchup(a, 0)
+            if not one_launch:
+                self._adam_catchup(a, 0)
         else:
             self._catch_up_all()
             a.last_step = None  # full batch: no unit falls behind
         if allreduce is None and self.pipelined_tail:
             self._finish_pending()
-            if self.overlap_tail and a.fuse_adam:
+            if one_launch:
+                # catch-up, site draws, likelihood, per-unit terms + Adam of this step and the pending tail of the
+                # previous one in a single launch; the tail of this step stays pending
+                prev = self._tail_args
+                self._sync_value = (self._sync_value + 1) & 0x3FFFFFFF
+                a.sync_value = self._sync_value or 1
+                _lib.check(self.lib.tq_cosmos_minibatch_step(C.byref(a), None if prev is None else C.byref(prev),
+                                                              self._stream()), "tq_cosmos_minibatch_step")
+                a.tail_kind = 1  # TQ_TAIL_ROWS16
+                self._tail_args = a
+            elif self.overlap_tail and a.fuse_adam:
                 prev = self._tail_args
                 _lib.check(self.lib.tq_cosmos_step_overlapped(C.byref(a), None if prev is None else C.byref(prev),
                                                               self._stream()), "tq_cosmos_step_overlapped")

@@ -131,11 +131,13 @@ def test_adam_matches_torch():
     assert torch.allclose(eng.params.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("minibatch", [False, True])
+@pytest.mark.parametrize("minibatch", [False, True, "one_launch"])
 def test_full_step_trajectory(minibatch):
     """Three complete HIP steps (device sampling + Adam); the oracle replays each step with the
     device's own draws and its own autograd + torch.optim.Adam."""
-    K, N, F = 2, 4, 6
+    # "one_launch": 3 AOIs x 17 frames per step = 51 units -> tq_cosmos_minibatch_step (4 workgroups, the last one ragged)
+    K, N, F = (2, 5, 24) if minibatch == "one_launch" else (2, 4, 6)
+    fbn = 17 if minibatch == "one_launch" else 4
     d = make_dataset(N=N, F=F, K=K)
     o = make_oracle(d, K, perturb=0.0)
     o.make_optim(lr=0.005)
@@ -144,7 +146,7 @@ def test_full_step_trajectory(minibatch):
     g = torch.Generator().manual_seed(5)
     for it in range(3):
         nd = torch.randperm(N, generator=g)[:3] if minibatch else torch.arange(N)
-        fd = torch.randperm(F, generator=g)[:4] if minibatch else torch.arange(F)
+        fd = torch.randperm(F, generator=g)[:fbn] if minibatch else torch.arange(F)
         eng.step(nd if minibatch else None, fd if minibatch else None)
         eng.join()  # full-batch steps leave their global tail pending for the next launch
         torch.cuda.synchronize()

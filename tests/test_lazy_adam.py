@@ -9,8 +9,8 @@ from helpers import make_dataset, make_oracle, oracle_to_engine
 from tapqir_amd.models.engine import CosmosEngine
 
 
-def engines(C=1, K=2, crosstalk=False):
-    d = make_dataset(N=6, F=16, C=C, K=K, seed=5)
+def engines(C=1, K=2, crosstalk=False, F=16):
+    d = make_dataset(N=6, F=F, C=C, K=K, seed=5)
     o = make_oracle(d, K, perturb=0.2, seed=2, crosstalk=crosstalk)
     out = []
     for lazy in (False, True):
@@ -27,18 +27,22 @@ def close(a, b, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("crosstalk", [False, True])
-def test_lazy_minibatch_adam_follows_the_dense_trajectory(crosstalk):
-    dense, lazy = engines(C=2 if crosstalk else 1, crosstalk=crosstalk)
+@pytest.mark.parametrize("crosstalk,F,fb", [(False, 16, 5), (True, 16, 5), (False, 40, 17)],
+                         ids=["cosmos", "crosstalk", "cosmos_one_launch_steps"])
+def test_lazy_minibatch_adam_follows_the_dense_trajectory(crosstalk, F, fb):
+    """fb >= 16: the lazy engine's minibatch steps run as tq_cosmos_minibatch_step (one launch: catch-up, draws,
+    likelihood, per-unit terms, pending tail), the dense engine's as the staged launches + dense Adam kernel."""
+    dense, lazy = engines(C=2 if crosstalk else 1, crosstalk=crosstalk, F=F)
+    assert lazy.fused_minibatch
     gen = torch.Generator().manual_seed(0)
-    touched = torch.zeros(6, 16, dtype=torch.bool)
+    touched = torch.zeros(6, F, dtype=torch.bool)
     losses = []
     for it in range(40):
         if it in (17, 31):  # full-batch steps in between: every unit catches up first
             ndx = fdx = None
         else:
             ndx = torch.randperm(6, generator=gen)[:2]
-            fdx = torch.randperm(16, generator=gen)[:5]
+            fdx = torch.randperm(F, generator=gen)[:fb]
             touched[ndx[:, None], fdx[None, :]] = True
         for eng in (dense, lazy):
             eng.step(ndx, fdx)
