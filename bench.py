@@ -411,7 +411,20 @@ def worker(args):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when the communicator is created; stdout carries the ONE JSON line of
+        # this script, so file descriptor 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            t = torch.zeros(1, device=dev)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         world = dist.get_world_size()  # what the process group says, not the environment
         rank = dist.get_rank()
     if world != args.gpus:
@@ -446,6 +459,8 @@ def worker(args):
     }
 
     if world == 1 and not args.quick:
+        # ---- roofline of the dominant kernel (same parameter regime as the headline steps) -----------
+        out["roofline"] = roofline_block(pb, h["ms_per_step"], dev)
         # ---- reference default minibatch operating point (main.py:1429-1430): nb=10, fb=512 ----------
         nb, fb = min(10, pb.N), min(512, pb.F)
         g = torch.Generator(device="cpu").manual_seed(0)
@@ -464,8 +479,6 @@ def worker(args):
         mb = sorted(mbs)[2]
         out["minibatch_10x512"] = {"ms_per_step": mb * 1e3, "steps_per_sec": 1 / mb, "aoi_frames_per_sec": nb * fb / mb,
                                    "protocol": "median of 5 blocks of 100 steps, fresh random subsample every step"}
-        # ---- roofline of the dominant kernel -----------------------------------------------------------
-        out["roofline"] = roofline_block(pb, h["ms_per_step"], dev)
         # ---- trained-parameter regime: guide concentrations shrink as the fit converges and other regimes of the
         # implicit reparameterisation gradients take over ------------------------------------
         if args.trained_steps > 0 and cfg == "c2" and args.offsets == "sim":

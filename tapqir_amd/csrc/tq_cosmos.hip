@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_co
 // step t-1), so the ~35 us latency chain of the tail hides behind the ~14 000 sampling workgroups of the same launch.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tq_sample_locals_tail_kernel(
     const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B, const int site_begin) {
-  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 / 4 = the same from rows of 256 /
-  // 16 units with the per-AOI sites folded in), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
+  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 = the same from rows of 256 units
+  // with the per-AOI sites folded in), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
   if (blockIdx.y == 0) {
     if (blockIdx.x != 0) return;
     __shared__ double s_w[4][TQ_MAX_NGSUM];
@@ -367,7 +367,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
       if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
-      else if (has_prev == 4) tq_rows_reduce_globals_body<16>(prev, s_w, s_e);
       else if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
       else tq_globals_from_gsum_body(prev, s_e);
       __syncthreads();
@@ -838,6 +837,12 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
     return TQ_ERR_ARG;
   }
   const int64_t B = tq_batch_units(*a);
+  if (prev && tq_prev_code(*prev) == 4) {
+    // (a pending single-launch minibatch step: its rows-of-16 tail is not carried by the sampling launch, whose register
+    // allocation every extra tail variant burdens)
+    if (int rc = tq_cosmos_tail(prev, stream)) return rc;
+    prev = nullptr;
+  }
   hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(2 + 4 * a->K)), dim3(256), 0,
                      (hipStream_t)stream, *a, prev ? *prev : *a, prev ? tq_prev_code(*prev) : 0, B, 0);
   if (int rc = check_launch("tq_sample_locals_tail_kernel")) return rc;
