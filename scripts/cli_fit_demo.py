@@ -1,8 +1,13 @@
 """Wall clock of `tapqir_amd fit` at the reference's default minibatch (10 AOIs x 512 frames) on simulated data."""
+import os
 import subprocess
 import sys
 import tempfile
 import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+os.environ["PYTHONPATH"] = ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")
 
 from tapqir_amd.utils.dataset import save
 from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
