@@ -12,10 +12,14 @@ with tempfile.TemporaryDirectory() as td:
     m = models["cosmos"](S=1, K=2, device="cuda", dtype="double")
     m.load(td)
     m.init(lr=0.005, nbatch_size=10, fbatch_size=512)
+    if os.environ.get("RATE_NO_CKPT"):
+        m.run_path = None  # no checkpoint file (convergence bookkeeping only)
     m.run(400, progress_bar=lambda r: r)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    m.run(4000, progress_bar=lambda r: r)
+    N = int(os.environ.get("RATE_ITERS", 4000))
+    m.run(N, progress_bar=lambda r: r)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"Model.run 10x512 on 400x1000: {4000 / dt:.0f} it/s ({dt / 4000 * 1e6:.1f} us per iteration, checkpoint every 200)")
+    NOTE = ", no file" if os.environ.get("RATE_NO_CKPT") else ""
+    print(f"Model.run 10x512 on 400x1000: {N / dt:.0f} it/s over {N} iterations ({dt / N * 1e6:.1f} us per iteration, checkpoint every 200{NOTE})")

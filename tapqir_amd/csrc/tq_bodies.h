@@ -347,6 +347,65 @@ TQ_HD void tq_adam_replay(const tq_cosmos_args& a, int64_t j, int s0, int s1) {
   a.exp_avg_sq[j] = v;
 }
 
+// The same replay with the per-step factors -- lr / (1 - beta1^s) and 1 / sqrt(1 - beta2^s), which depend on the step
+// only -- read from a table tab[2 (s - T0)], tab[2 (s - T0) + 1] for s >= T0 (tq_adam_bias_table; the single-launch
+// minibatch step keeps it in LDS).  Removes the fp64 power chain, two conversions and two of the four transcendentals
+// from every replayed step; steps before T0 (units that sat out more than the table's length) take the direct form.
+#define TQ_BIAS_TABLE_STEPS 1024
+TQ_HD void tq_adam_bias_entry(const tq_cosmos_args& a, int s, float* lr1, float* rs2) {
+  *rs2 = TQ_FRCP(TQ_FSQRT((float)(1.0 - tq_powi(a.beta2_d, s))));
+  *lr1 = a.lr * TQ_FRCP((float)(1.0 - tq_powi(a.beta1_d, s)));
+}
+TQ_HD void tq_adam_replay_tab_given(const tq_cosmos_args& a, int64_t j, int s0, int s1, const float* tab, int T0,
+                                    float p, float m, float v);
+TQ_HD void tq_adam_replay_tab(const tq_cosmos_args& a, int64_t j, int s0, int s1, const float* tab, int T0) {
+  if (s0 > s1) return;
+  tq_adam_replay_tab_given(a, j, s0, s1, tab, T0, a.params[j], a.exp_avg[j], a.exp_avg_sq[j]);
+}
+// (p, m, v: the element's current values, loaded by the caller ahead of time)
+TQ_HD void tq_adam_replay_tab_given(const tq_cosmos_args& a, int64_t j, int s0, int s1, const float* tab, int T0,
+                                    float p, float m, float v) {
+  if (s0 > s1) return;
+  int s = s0;
+  for (; s < T0 && s <= s1; ++s) {
+    float lr1, rs2;
+    tq_adam_bias_entry(a, s, &lr1, &rs2);
+    m = a.beta1 * m;
+    v = a.beta2 * v;
+    p = p - lr1 * m * TQ_FRCP(TQ_FSQRT(v) * rs2 + a.adam_eps);
+  }
+  bool live = true;
+  while (live && s + 8 <= s1 + 1) {
+    float inc = 0.0f;
+    const float* t = tab + 2 * (s - T0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      m = a.beta1 * m;
+      v = a.beta2 * v;
+      inc = t[2 * k] * m * TQ_FRCP(TQ_FSQRT(v) * t[2 * k + 1] + a.adam_eps);
+      p = p - inc;
+    }
+    s += 8;
+    live = !(fabsf(inc) < fmaxf(1.4901161e-08f * fabsf(p), 3e-9f));
+  }
+  if (live) {
+    for (; s <= s1; ++s) {
+      const float* t = tab + 2 * (s - T0);
+      m = a.beta1 * m;
+      v = a.beta2 * v;
+      p = p - t[0] * m * TQ_FRCP(TQ_FSQRT(v) * t[1] + a.adam_eps);
+    }
+  }
+  if (s <= s1) {
+    const int n = s1 - s + 1;
+    m *= (float)tq_powi((double)a.beta1, n);
+    v *= (float)tq_powi((double)a.beta2, n);
+  }
+  a.params[j] = p;
+  a.exp_avg[j] = m;
+  a.exp_avg_sq[j] = v;
+}
+
 TQ_HD void tq_body_adam(const tq_cosmos_args& a, int64_t j) {
   tq_adam_apply(a, j, a.params[j], a.grad[j]);
   if (a.zero_grad) a.grad[j] = 0.0f;

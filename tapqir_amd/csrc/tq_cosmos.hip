@@ -310,20 +310,53 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
   // per-AOI sites: frame sums = sums over the rows that overlap the AOI; prior terms; gradient of the AOI parameters
   const int nac = a.nb * a.C;
-  for (int ac = threadIdx.x; ac < nac; ac += 256) {
-    const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;  // position of the AOI in the batch
-    const int c = ac - (int)ai * a.C;
-    const uint32_t r_lo = (ai * FC) / UPR, r_hi = ((ai + 1) * FC - 1) / UPR;
-    float s1 = 0.0f, s2 = 0.0f;
-    for (uint32_t r = r_lo; r <= r_hi; ++r) {
-      const int slot = (r * UPR) / FC == ai ? 0 : 1;
-      const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
-      s1 += row[0];
-      s2 += row[1];
+  if constexpr (UPR == 16) {
+    // rows of 16 units: an AOI of the minibatch spans fb C / 16 rows (32 at the default 10 x 512) and this workgroup is
+    // the critical path of the step -- 16 lanes share the rows of one (AOI, channel), so the loads of an AOI are two
+    // round trips instead of 32 in sequence
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    for (int ac0 = 0; ac0 < nac; ac0 += 16) {
+      const int ac = ac0 + grp;
+      const bool on = ac < nac;
+      const uint32_t ai = on ? (uint32_t)ac / (uint32_t)a.C : 0u;
+      const int c = on ? ac - (int)ai * a.C : 0;
+      float s1 = 0.0f, s2 = 0.0f;
+      if (on) {
+        const uint32_t r_lo = (ai * FC) / UPR, r_hi = ((ai + 1) * FC - 1) / UPR;
+        for (uint32_t r = r_lo + gl; r <= r_hi; r += 16) {
+          const int slot = (r * UPR) / FC == ai ? 0 : 1;
+          const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
+          s1 += row[0];
+          s2 += row[1];
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 16);
+        s2 += __shfl_xor(s2, o, 16);
+      }
+      if (on && gl == 0) {
+        float e;
+        tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
+        acc[TQ_GS_ELBO] += (double)e;
+      }
     }
-    float e;
-    tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
-    acc[TQ_GS_ELBO] += (double)e;
+  } else {
+    for (int ac = threadIdx.x; ac < nac; ac += 256) {
+      const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;  // position of the AOI in the batch
+      const int c = ac - (int)ai * a.C;
+      const uint32_t r_lo = (ai * FC) / UPR, r_hi = ((ai + 1) * FC - 1) / UPR;
+      float s1 = 0.0f, s2 = 0.0f;
+      for (uint32_t r = r_lo; r <= r_hi; ++r) {
+        const int slot = (r * UPR) / FC == ai ? 0 : 1;
+        const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
+        s1 += row[0];
+        s2 += row[1];
+      }
+      float e;
+      tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
+      acc[TQ_GS_ELBO] += (double)e;
+    }
   }
   for (int64_t r = threadIdx.x; r < nrows; r += 256) {
 #pragma unroll
@@ -413,8 +446,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   const int tid = threadIdx.x;
 #ifdef TQ_MB_STAMPS
 #define TQ_STAMP(n) if (tid == 0 && blockIdx.x == TQ_MB_STAMPS) ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();
+#define TQ_TAIL_STAMP(n) if (tid == 0) ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();
 #else
 #define TQ_STAMP(n)
+#define TQ_TAIL_STAMP(n)
 #endif
   TQ_STAMP(0)
   if (tid == 0) s_ticket = __hip_atomic_fetch_add(&a.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,17 +460,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   if (ticket == 0) {  // the extra workgroup of the grid: owns no units
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+    TQ_TAIL_STAMP(8)
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
       if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
       else if (has_prev == 4) tq_rows_reduce_globals_body<16>(prev, s_w, s_e);
       else tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
       __syncthreads();
+      TQ_TAIL_STAMP(9)
       const int64_t total = tq_num_params(prev);
       for (int64_t j = tq_aoi_base(prev) + tid; j < total; j += 256) tq_body_adam(prev, j);
       __threadfence_block();
       __syncthreads();
     }
+    TQ_TAIL_STAMP(10)
     const int ns = tq_num_gsites(a);
     if ((tid & 63) == 0)
       for (int s = tid >> 6; s < ns; s += 4) tq_body_sample_globals(a, s);
@@ -447,6 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&a.sync[1], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    TQ_TAIL_STAMP(11)
     // re-arm the ticket counter when every workgroup has taken its ticket
     if (tid == 0) {
       const int done = __hip_atomic_fetch_add(&a.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -463,13 +502,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   constexpr int NL = TQ_NLOCAL(K), NS = 1 + 4 * K;
   TQ_STAMP(7)
   if (a.last_step) {
-    for (int e = tid; e < NL * TQ_UNITS_PER_BLOCK; e += 256) {
+    // per-step bias-correction factors of the last TQ_BIAS_TABLE_STEPS steps, shared by every element of the workgroup
+    __shared__ float s_bias[2 * TQ_BIAS_TABLE_STEPS];
+    const int s1 = (int)a.step;
+    const int T0 = s1 - (TQ_BIAS_TABLE_STEPS - 1) > 1 ? s1 - (TQ_BIAS_TABLE_STEPS - 1) : 1;
+    // the chain of dependent loads of every element of this thread (subsample index -> unit -> last step -> values) is
+    // issued first and overlaps with the table build
+    constexpr int NPASS = (NL * TQ_UNITS_PER_BLOCK + 255) / 256;
+    int64_t ej[NPASS];
+    int es0[NPASS];
+    float ep[NPASS], em[NPASS], ev[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int e = tid + 256 * q;
       const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
-      if (i < B) {
+      ej[q] = -1;
+      es0[q] = s1 + 1;
+      ep[q] = em[q] = ev[q] = 0.0f;
+      if (e < NL * TQ_UNITS_PER_BLOCK && i < B) {
         const int64_t u = tq_decode_unit(a, i).u;
-        tq_adam_replay(a, (int64_t)(e >> 4) * tq_num_units(a) + u, a.last_step[u] + 1, (int)a.step);
+        ej[q] = (int64_t)(e >> 4) * tq_num_units(a) + u;
+        es0[q] = a.last_step[u] + 1;
+        ep[q] = a.params[ej[q]];
+        em[q] = a.exp_avg[ej[q]];
+        ev[q] = a.exp_avg_sq[ej[q]];
       }
     }
+    {
+      double pw1 = tq_powi(a.beta1_d, T0 + tid), pw2 = tq_powi(a.beta2_d, T0 + tid);
+      const double b1_256 = tq_powi(a.beta1_d, 256), b2_256 = tq_powi(a.beta2_d, 256);
+      for (int e = tid; e < TQ_BIAS_TABLE_STEPS; e += 256) {  // same expressions as tq_adam_bias_entry
+        if (T0 + e <= s1) {
+          s_bias[2 * e] = a.lr * TQ_FRCP((float)(1.0 - pw1));
+          s_bias[2 * e + 1] = TQ_FRCP(TQ_FSQRT((float)(1.0 - pw2)));
+        }
+        pw1 *= b1_256;
+        pw2 *= b2_256;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q)
+      if (ej[q] >= 0) tq_adam_replay_tab_given(a, ej[q], es0[q], s1, s_bias, T0, ep[q], em[q], ev[q]);
     __syncthreads();
   }
   TQ_STAMP(1)

@@ -189,6 +189,8 @@ class Model:
         finally:
             self._in_run = False
             self._join_checkpoint_writer()
+            if getattr(self, "_ckpt_file_stale", False) and self.run_path is not None:
+                self._write_state_file(wait=True)  # the file of the last checkpoint(s) was left to this point
         self.iter_loss = self.last_loss()
 
     def set_rng_seed(self, seed):
@@ -232,15 +234,7 @@ class Model:
             if crit:
                 self.converged = True
         if self.run_path is not None:
-            self.run_path.mkdir(parents=True, exist_ok=True)
-            payload = {
-                "iter": self.iter,
-                "params": self._param_store_state(),
-                "optimizer": self._optim_state(),
-                "rolling": {k: list(v) for k, v in self._rolling.items()},  # model.py:279 stores the deques
-                "convergence_status": self.converged,
-            }
-            self._write_checkpoint(payload, self.run_path / f"{self.name}_model.tpqr")
+            self._write_state_file()
         if writer is not None:
             writer.add_scalar("-ELBO", self.iter_loss, self.iter)
             for name, val in cparams.items():
@@ -253,30 +247,74 @@ class Model:
                         name, {f"{i}_{j}": k.item() for i, v in enumerate(val) for j, k in enumerate(v)}, self.iter)
         logger.debug(f"Iteration #{self.iter}: Successful.")
 
-    # A checkpoint of a c2-sized fit is 86 MB: 9 ms to bring the three flat buffers to the host, ~32 ms for torch.save --
-    # three times the 13 ms that the 200 minibatch steps between two checkpoints take.  The host copy is taken here, the
-    # file is written by a thread (to a temporary name, then renamed) while the fit goes on; the next checkpoint, the end
-    # of run(), load_checkpoint() and compute_stats() wait for it.
-    def _write_checkpoint(self, payload, target):
-        import threading
+    # A checkpoint of a c2-sized fit is 86 MB: 9 ms to bring the three flat buffers to the host and ~32 ms for
+    # torch.save, against the 13 ms that the 200 minibatch steps between two checkpoints take.  Outside run() (and on the
+    # CPU) the file is written here and is complete when save_checkpoint returns.  Inside run() on a GPU the state is
+    # snapshotted on the device and written by a helper process (tapqir_amd/utils/ckpt_writer.py), one file at a time: a
+    # checkpoint that finds the previous file still being written leaves the file to a later one, and run() writes
+    # the final state when it ends.  The bookkeeping of a checkpoint (NaN check, rolling windows, convergence) is never
+    # skipped.  TAPQIR_AMD_CKPT_PROCESS=0 keeps everything in-process.
+    def _manifest(self):
+        eng = self.engine
+        return {
+            "slots": {k: (int(off), tuple(int(x) for x in shape)) for k, (off, shape) in eng.layout.slots().items()},
+            "constraints": eng.layout.constraints(),
+            "adam": {"step": eng.adam_step, "lr": eng.lr, "betas": tuple(eng.betas), "eps": eng.adam_eps},
+            "iter": self.iter,
+            "rolling": {k: list(v) for k, v in self._rolling.items()},  # model.py:279 stores the deques
+            "convergence_status": self.converged,
+        }
 
+    def _write_state_file(self, wait=None):
+        """Write ``<run_path>/<name>_model.tpqr`` with the current state (model.py:272-289)."""
+        import os
+
+        self.run_path.mkdir(parents=True, exist_ok=True)
+        target = self.run_path / f"{self.name}_model.tpqr"
+        eng = self.engine
+        wait = (not getattr(self, "_in_run", False)) if wait is None else wait
+        w = getattr(self, "_ckpt_process", None)
+        if w is not None and w.n != eng.params.numel():
+            w = None
+        if w is not None and (w.busy() or w.ready()):
+            if not wait and w.busy():
+                self._ckpt_file_stale = True  # a later checkpoint, or the end of run(), writes a newer state
+                return
+            w.submit(eng.params, eng.exp_avg, eng.exp_avg_sq, self._manifest(), target)
+            self._ckpt_file_stale = False
+            if wait:
+                w.join()
+            return
+        if w is not None and not wait:  # the helper process is still starting (~1 s): leave the file to a later checkpoint
+            self._ckpt_file_stale = True
+            return
+        if (w is None and not wait and eng.params.device.type == "cuda"
+                and os.environ.get("TAPQIR_AMD_CKPT_PROCESS", "1") != "0"):
+            # first file of a run(): written here, while the helper process for the following ones starts
+            from tapqir_amd.utils.ckpt_writer import CheckpointWriter
+
+            self._ckpt_process = CheckpointWriter(eng.params.numel(), eng.params.device)
         self._join_checkpoint_writer()
+        from tapqir_amd.utils.ckpt_writer import write_file
 
-        def write():
-            tmp = target.with_suffix(target.suffix + ".tmp")
-            torch.save(payload, tmp)
-            tmp.replace(target)
+        payload = {
+            "iter": self.iter,
+            "params": self._param_store_state(),
+            "optimizer": self._optim_state(),
+            "rolling": {k: list(v) for k, v in self._rolling.items()},
+            "convergence_status": self.converged,
+        }
+        write_file(payload, target)
+        self._ckpt_file_stale = False
 
-        self._ckpt_writer = threading.Thread(target=write, name="tapqir-checkpoint")
-        self._ckpt_writer.start()
-        if not getattr(self, "_in_run", False):
-            self._join_checkpoint_writer()  # outside run() the file is complete when save_checkpoint returns
-
-    def _join_checkpoint_writer(self):
-        t = getattr(self, "_ckpt_writer", None)
-        if t is not None:
-            t.join()
-            self._ckpt_writer = None
+    def _join_checkpoint_writer(self, close=False):
+        w = getattr(self, "_ckpt_process", None)
+        if w is not None:
+            if close:
+                self._ckpt_process = None
+                w.close()
+            else:
+                w.join()
 
     def _param_store_state(self):
         """Same payload shape as pyro.get_param_store().get_state()."""
