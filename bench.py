@@ -324,6 +324,33 @@ def cpu_baseline(data, K, nb, fb, steps=5, warmup=2, dtype="float64", threads=No
             "steps_per_sec_at_sample": 1 / med}
 
 
+def time_fused_kernel(eng, launches):
+    """Average duration of tq_pixel_unit_kernel (pixel kernel + per-unit terms + Adam of a full-batch step in one launch),
+    HIP events on its launch stream.  Every launch applies an Adam step to the local parameters: they are put back."""
+    import torch
+
+    from tapqir_amd import _lib
+
+    eng.join()
+    saved = (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone())
+    a = eng.make_args()
+    a.fuse_adam, a.pixel_mode, a.last_step = 1, 2, None
+    eng.call("cosmos_sample_globals", a)
+    eng.call("cosmos_sample_locals", a)
+    for _ in range(2):
+        eng.call("cosmos_pixel_unit", a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        eng.call("cosmos_pixel_unit", a)
+    e1.record()
+    e1.synchronize()
+    eng.params.copy_(saved[0])
+    eng.exp_avg.copy_(saved[1])
+    eng.exp_avg_sq.copy_(saved[2])
+    return e0.elapsed_time(e1) / launches * 1e-3
+
+
 def roofline_block(pb, ms_per_step, dev):
     import torch
 
@@ -358,6 +385,15 @@ def roofline_block(pb, ms_per_step, dev):
         out["with_gradient_outputs"] = {"bytes_per_unit": bb, "achieved": units * bb / t_fb / 1e9,
                                         "frac": units * bb / t_fb / 1e9 / HBM_PEAK_GBS,
                                         "note": "bytes_per_unit + K m_probs logits read + (2+4K) gradient rows written"}
+    if getattr(eng, "fuse_unit", False) and eng._fusable():
+        # what the timed steps actually launch: pixel kernel + per-unit terms + Adam as one kernel, whose algorithmic
+        # bytes are those of the whole step (tile + target position + read/write of every local parameter and moment)
+        t_pu = time_fused_kernel(eng, 10)
+        out["step_kernel"] = {"kernel": "tq_pixel_unit_kernel<K,P> (the pixel kernel above + per-unit ELBO terms, gradients and "
+                                        "Adam of the same 64 units, one launch; chosen over two launches by timing both on "
+                                        f"this box: {[round(t, 4) for t in getattr(eng, 'step_times_ms', [])]} ms per step)",
+                              "bytes_per_unit": sb, "units_per_launch": tot_units, "avg_launch_ms": t_pu * 1e3,
+                              "achieved": tot_units * sb / t_pu / 1e9, "frac": tot_units * sb / t_pu / 1e9 / HBM_PEAK_GBS}
     if eng.O > 1:
         # the offset-histogram kernel is bound by the transcendental pipe, not by HBM: (K+1) + 1 exp2/log2 per
         # (offset, pixel); peak = v_exp_f32 issue rate of profiles/r01_valu_issue_rates.txt (8 cycles per wave64) x 1024 SIMDs

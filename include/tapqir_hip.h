@@ -247,7 +247,7 @@ typedef struct {
   /* lazy Adam of minibatch steps (tq_cosmos_adam_catchup) */
   int32_t* last_step;          /* [Nt*F*C] Adam step at which the local parameters of a unit were last updated, or NULL */
   double beta1_d, beta2_d;     /* the Adam betas in double: 1 - beta^s of the replayed steps is formed like the host's */
-  int32_t pixel_mode;          /* passed on to tq_ksmogn_args.pixel_mode */
+  int32_t pixel_mode;          /* 0 / 1: passed on to tq_ksmogn_args.pixel_mode; TQ_PIXEL_FUSED_UNIT (2): see tq_cosmos_pixel_unit */
   int32_t tail_kind;           /* how the pending tail of THIS step finds its partial sums: TQ_TAIL_AUTO (what tq_cosmos_step /
                                   _step_overlapped / _elbo_grads wrote) or TQ_TAIL_ROWS16 (the step ran as
                                   tq_cosmos_minibatch_step); the host sets it on the struct it later passes as `prev` / to
@@ -259,6 +259,7 @@ typedef struct {
 
 #define TQ_TAIL_AUTO 0
 #define TQ_TAIL_ROWS16 1
+#define TQ_PIXEL_FUSED_UNIT 2      /* tq_cosmos_args.pixel_mode: pixel + per-unit kernel of a full-batch step in one launch */
 
 int64_t tq_globals_size(void);
 int64_t tq_gbase_size(void);
@@ -300,6 +301,15 @@ int tq_cosmos_adam_catchup(const tq_cosmos_args* a, int32_t all_units, void* str
  * reading elbo_out / the per-AOI and global parameters.  prev == NULL: nothing pending (first step). */
 int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
 int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
+/* With a->pixel_mode = TQ_PIXEL_FUSED_UNIT, tq_cosmos_step / tq_cosmos_step_overlapped run the likelihood and the
+ * per-unit terms + Adam of a full-batch step as ONE launch: a wave renders its tile of 64 units and goes on to the
+ * per-unit routine of the same units with the pixel results in registers (the pixel phase is bound by VALU issue, the
+ * per-unit phase by HBM: waves in different phases overlap).  Full-batch cosmos steps with fuse_adam, K <= 2, one offset
+ * value, P in {14, 20}, images_il and pixstats given, F * C >= 256; anything else is refused (TQ_ERR_ARG).  Same results
+ * as the two-launch form up to the order of the fp32 partial sums (rows of 64 units instead of 256).
+ * tq_cosmos_pixel_unit is that launch alone (a stage export like tq_cosmos_elbo_grads: draws and global tables of `a`
+ * must be in place; it applies the Adam step of the local parameters and leaves the rows for the tail). */
+int tq_cosmos_pixel_unit(const tq_cosmos_args* a, void* stream);
 /* Minibatch steps (the reference's default operating point is 10 AOIs x 512 frames = 5120 units, main.py:1428-1431) in
  * ONE launch: every workgroup takes 16 units through lazy-Adam catch-up, guide-site draws, likelihood and per-unit terms +
  * Adam; the first workgroup to start also runs the pending tail of `prev` (or nothing) and the global draws of `a`, which

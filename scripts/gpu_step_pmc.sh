@@ -3,7 +3,7 @@
 # --kernel-trace only).  Output: gpurun_out/steppmc/summary.txt
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/steppmc
+OUT=$R/gpurun_out/${STEPOUT:-steppmc}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -14,4 +14,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS
 done
 python3 $R/scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 find $OUT -name "*.csv" -size +2M -delete
-grep -A16 "^tq_unit_rows\|^tq_sample_locals_tail" $OUT/summary.txt
+grep -A16 "${STEPGREP:-^tq_unit_rows\|^tq_sample_locals_tail}" $OUT/summary.txt

@@ -138,7 +138,7 @@ EXPORTS = [
     "tq_globals_size", "tq_gbase_size", "tq_cosmos_nblk", "tq_cosmos_param_count",
     "tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
     "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_step_overlapped", "tq_cosmos_tail", "tq_cosmos_tail_reduced", "tq_cosmos_sample_locals_range",
-    "tq_cosmos_blk_floats", "tq_cosmos_minibatch_step",
+    "tq_cosmos_blk_floats", "tq_cosmos_minibatch_step", "tq_cosmos_pixel_unit",
     "tq_cosmos_probs", "tq_glimpse_extract", "tq_ksmogn_rsample", "tq_snr_chi2",
 ]
 
@@ -184,7 +184,8 @@ def load():
     lib.tq_ksmogn_log_prob.argtypes = [C.POINTER(KsmognArgs), C.c_void_p]
     lib.tq_ksmogn_log_prob.restype = C.c_int
     for name in ("tq_cosmos_sample_globals", "tq_cosmos_sample_locals", "tq_cosmos_elbo_grads",
-                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_tail"):
+                 "tq_cosmos_globals_grad", "tq_cosmos_adam", "tq_cosmos_adam_catchup", "tq_cosmos_step", "tq_cosmos_tail",
+                 "tq_cosmos_pixel_unit"):
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(CosmosArgs), C.c_void_p]
         fn.restype = C.c_int

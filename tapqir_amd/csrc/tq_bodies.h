@@ -114,7 +114,8 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
   }
   a.lat[t] = val;
 #pragma unroll
-  for (int j = 0; j < TQ_NSITE_TERMS; ++j) a.site[(int64_t)j * NS + t] = terms[j];
+  for (int j = 0; j < TQ_NSITE_TERMS; ++j)
+    if (j < 5 || site > K) a.site[(int64_t)j * NS + t] = terms[j];  // Gamma sites have five terms: slot 5 is never read
 }
 
 TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO);
@@ -126,8 +127,10 @@ TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, floa
 // written to a.aoi_part (the fused step kernel sums them per workgroup).
 // LATE_MOMENTS: the Adam moments are loaded after the gradient arithmetic instead of ahead of it (the fused step kernel
 // runs at twice the occupancy of tq_unit_kernel and cannot afford the 4K+... registers that holding them costs).
+// pixv != nullptr: the pixel kernel's results for this unit (the rows of a.pix, in row order) are taken from there (the
+// fused pixel + per-unit kernel hands them over in registers).
 template <int K, bool LATE_MOMENTS = false>
-TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* aoi2 = nullptr) {
+TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* aoi2 = nullptr, const float* pixv = nullptr) {
   constexpr int M = 1 << K;
   constexpr int NL = TQ_NLOCAL(K);
   const int64_t B = tq_batch_units(a), U = tq_num_units(a);
@@ -156,24 +159,24 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
     in.y[k] = a.lat[(int64_t)(1 + 3 * K + k) * B + i];
   }
 #pragma unroll
-  for (int mi = 0; mi < M; ++mi) in.ll[mi] = a.pix[(int64_t)mi * B + i];
-  in.gb = a.pix[(int64_t)M * B + i];
-  const float g_gain = a.pix[(int64_t)(M + 1) * B + i];
+  for (int mi = 0; mi < M; ++mi) in.ll[mi] = pixv ? pixv[mi] : a.pix[(int64_t)mi * B + i];
+  in.gb = pixv ? pixv[M] : a.pix[(int64_t)M * B + i];
+  const float g_gain = pixv ? pixv[M + 1] : a.pix[(int64_t)(M + 1) * B + i];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    in.gh[k] = a.pix[(int64_t)(M + 2 + k) * B + i];
-    in.gw[k] = a.pix[(int64_t)(M + 2 + K + k) * B + i];
-    in.gx[k] = a.pix[(int64_t)(M + 2 + 2 * K + k) * B + i];
-    in.gy[k] = a.pix[(int64_t)(M + 2 + 3 * K + k) * B + i];
+    in.gh[k] = pixv ? pixv[M + 2 + k] : a.pix[(int64_t)(M + 2 + k) * B + i];
+    in.gw[k] = pixv ? pixv[M + 2 + K + k] : a.pix[(int64_t)(M + 2 + K + k) * B + i];
+    in.gx[k] = pixv ? pixv[M + 2 + 2 * K + k] : a.pix[(int64_t)(M + 2 + 2 * K + k) * B + i];
+    in.gy[k] = pixv ? pixv[M + 2 + 3 * K + k] : a.pix[(int64_t)(M + 2 + 3 * K + k) * B + i];
   }
   const int64_t NS = (int64_t)(1 + 4 * K) * B;
 #pragma unroll
   for (int j = 0; j < TQ_NSITE_TERMS; ++j) {
     const float* sj = a.site + (int64_t)j * NS;
-    in.sb[j] = sj[i];
+    in.sb[j] = j < 5 ? sj[i] : 0.0f;  // (Gamma sites: five terms)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      in.sh[k][j] = sj[(int64_t)(1 + k) * B + i];
+      in.sh[k][j] = j < 5 ? sj[(int64_t)(1 + k) * B + i] : 0.0f;
       in.sw[k][j] = sj[(int64_t)(1 + K + k) * B + i];
       in.sx[k][j] = sj[(int64_t)(1 + 2 * K + k) * B + i];
       in.sy[k][j] = sj[(int64_t)(1 + 3 * K + k) * B + i];

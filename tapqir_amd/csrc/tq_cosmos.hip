@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void tq_tail_reduced_kernel(const tq_cosmos_ar
 #define TQ_ROWS_MAXCOL (TQ_ROWS_GCOL + TQ_MAX_NGSUM)
 
 #include "tq_ksmogn_dev.h"
+#include "tq_ksmogn_il2.h"
 
 // (host) does this step use the rows layout?  TAPQIR_AMD_ROWS=0 keeps the flat layout + tq_aoi_kernel (A/B timing)
 static bool tq_rows_layout(const tq_cosmos_args& a) {
@@ -241,6 +242,11 @@ static bool tq_rows_layout(const tq_cosmos_args& a) {
 static int tq_prev_code(const tq_cosmos_args& prev) {
   if (prev.tail_kind == TQ_TAIL_ROWS16) return 4;
   return tq_rows_layout(prev) ? 3 : 1;
+}
+// units per row of a step with rows (codes 3 / 4): 16 (single-launch minibatch step), 64 (fused pixel + per-unit
+// kernel), TQ_UNIT_BLOCK (tq_unit_rows_kernel)
+__host__ __device__ __forceinline__ int tq_rows_upr(const tq_cosmos_args& a) {
+  return a.tail_kind == TQ_TAIL_ROWS16 ? 16 : (a.pixel_mode == TQ_PIXEL_FUSED_UNIT ? 64 : TQ_UNIT_BLOCK);
 }
 
 template <int K>
@@ -295,13 +301,75 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
   }
 }
 
+// Fused pixel + per-unit kernel of full-batch steps (pixel_mode = TQ_PIXEL_FUSED_UNIT): a wave renders its tile of 64
+// units (tq_il2_lane, the routine of tq_ksmogn_il2_kernel) and goes straight on to the per-unit terms + Adam of the same
+// 64 units, lane for lane.  The pixel phase is bound by VALU issue (PMC: ~75 % busy) and the per-unit phase by HBM
+// (4.3 TB/s of traffic at 33 % VALU busy): as two launches they run one after the other, here the waves of a SIMD are in
+// different phases most of the time.  The pixel results go from one phase to the next in registers (56 B per unit
+// neither written nor read), a launch boundary is gone, and the row of partial sums is per wave (rows of 64 units).
+template <int K, int P>
+__global__ __launch_bounds__(64, 2) void tq_pixel_unit_kernel(const tq_ksmogn_args k, const tq_cosmos_args a, const int64_t B) {
+  float pixv[TQ_PIXOUT(K)];
+#pragma unroll
+  for (int j = 0; j < TQ_PIXOUT(K); ++j) pixv[j] = 0.0f;
+  tq_il2_lane<K, P, true>(k, B, pixv);
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint32_t FC = (uint32_t)(a.F * a.C);
+  const uint32_t n0 = ((uint32_t)blockIdx.x * 64u) / FC;  // AOI of the wave's first unit
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  float part[TQ_MAX_NGSUM], aoi[TQ_ROWS_GCOL];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < TQ_ROWS_GCOL; ++j) aoi[j] = 0.0f;
+  if (i < B) {
+    float aoi2[2];
+    tq_body_unit<K>(a, i, part, aoi2, pixv);
+    const uint32_t n = (uint32_t)i / FC;
+    const int c = (int)((uint32_t)i % (uint32_t)a.C);
+    const int slot = n == n0 ? 0 : 1;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+      for (int q = 0; q < TQ_MAXQ; ++q) {
+        const bool mine = sl == slot && q == c;
+        aoi[sl * TQ_ROWS_AOICOL + 2 * q] = mine ? aoi2[0] : 0.0f;
+        aoi[sl * TQ_ROWS_AOICOL + 2 * q + 1] = mine ? aoi2[1] : 0.0f;
+      }
+    }
+  }
+  float* row = a.blk_part + (int64_t)blockIdx.x * ncol;
+#pragma unroll
+  for (int j = 0; j < TQ_ROWS_GCOL; ++j) {
+    const bool used = (j % TQ_ROWS_AOICOL) < 2 * a.C;
+    const float sum = used ? tq_wave_sum(aoi[j]) : 0.0f;
+    if (threadIdx.x == 0) row[j] = sum;
+  }
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const float sum = tq_wave_sum(part[j]);
+      if (threadIdx.x == 0) row[TQ_ROWS_GCOL + j] = sum;
+    }
+  }
+}
+
+// (host) launch of the fused kernel; the caller has checked that the step qualifies (tq_fused_pixel_unit)
+static bool tq_fused_pixel_unit(const tq_cosmos_args& a) {
+  const int64_t B = tq_batch_units(a);
+  return a.pixel_mode == TQ_PIXEL_FUSED_UNIT && tq_rows_layout(a) && !a.crosstalk && a.K <= 2 && a.O == 1 && a.pixstats &&
+         a.images_il && (a.P == 14 || a.P == 20) && B >= a.il_min_units;
+}
+static int launch_pixel_unit(const tq_cosmos_args* a, void* stream);
+
 // Tail of a step whose per-unit kernel wrote such rows (ONE workgroup of 256 threads): per-AOI sites from the rows that
 // overlap the AOI, cross-unit sums in fp64, global sites and the total ELBO.
 // UPR = units per row: TQ_UNIT_BLOCK (tq_unit_rows_kernel) or 16 (the single-launch minibatch step)
-template <int UPR>
+template <int UPR_T>
 __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
   const int64_t B = tq_batch_units(a);
+  const uint32_t UPR = UPR_T == 16 ? 16u : (uint32_t)tq_rows_upr(a);  // (one instance serves rows of 64 and of 256)
   const int64_t nrows = (B + UPR - 1) / UPR;
   const uint32_t FC = (uint32_t)(a.fb * a.C);  // units of one AOI of the batch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -310,7 +378,7 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
   // per-AOI sites: frame sums = sums over the rows that overlap the AOI; prior terms; gradient of the AOI parameters
   const int nac = a.nb * a.C;
-  if constexpr (UPR == 16) {
+  if constexpr (UPR_T == 16) {
     // rows of 16 units: an AOI of the minibatch spans fb C / 16 rows (32 at the default 10 x 512) and this workgroup is
     // the critical path of the step -- 16 lanes share the rows of one (AOI, channel), so the loads of an AOI are two
     // round trips instead of 32 in sequence
@@ -762,6 +830,21 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   return tq_ksmogn_log_prob(&k, stream);
 }
 
+static int launch_pixel_unit(const tq_cosmos_args* a, void* stream) {
+  const int64_t B = tq_batch_units(*a);
+  const tq_ksmogn_args k = cosmos_ksmogn_args(a);
+  const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->K == 1) {
+    if (a->P == 14) hipLaunchKernelGGL((tq_pixel_unit_kernel<1, 14>), grid, block, 0, st, k, *a, B);
+    else hipLaunchKernelGGL((tq_pixel_unit_kernel<1, 20>), grid, block, 0, st, k, *a, B);
+  } else {
+    if (a->P == 14) hipLaunchKernelGGL((tq_pixel_unit_kernel<2, 14>), grid, block, 0, st, k, *a, B);
+    else hipLaunchKernelGGL((tq_pixel_unit_kernel<2, 20>), grid, block, 0, st, k, *a, B);
+  }
+  return check_launch("tq_pixel_unit_kernel");
+}
+
 // rows: AOI-aligned per-unit kernel whose tail also finishes the per-AOI sites (tq_unit_rows_kernel; full-batch steps
 // that finish with tq_cosmos_tail or inside the next tq_cosmos_step_overlapped)
 static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_sums, bool rows = false) {
@@ -774,6 +857,14 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
   hipStream_t st = (hipStream_t)stream;
   const int K = a->K;
   const int64_t B = tq_batch_units(*a);
+  if (a->pixel_mode == TQ_PIXEL_FUSED_UNIT) {  // pixel + per-unit kernel in one launch (rows of 64 units)
+    if (!rows || !tq_fused_pixel_unit(*a)) {
+      tq_set_error("tq_cosmos: pixel_mode = TQ_PIXEL_FUSED_UNIT needs a full-batch cosmos step with fused Adam, K <= 2, one "
+                   "offset value, P in {14, 20}, the interleaved images and the pixel statistics");
+      return TQ_ERR_ARG;
+    }
+    return launch_pixel_unit(a, stream);
+  }
   // 1. pixel kernel
   if (int rc = launch_likelihood(a, stream)) return rc;
   // 2. per-unit sites
@@ -806,6 +897,15 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
 }
 
 extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) { return elbo_grads_impl(a, stream, true); }
+
+extern "C" int tq_cosmos_pixel_unit(const tq_cosmos_args* a, void* stream) {
+  if (int rc = check_args(a, "pixel_unit")) return rc;
+  if (a->pixel_mode != TQ_PIXEL_FUSED_UNIT) {
+    tq_set_error("tq_cosmos_pixel_unit: pixel_mode must be TQ_PIXEL_FUSED_UNIT");
+    return TQ_ERR_ARG;
+  }
+  return elbo_grads_impl(a, stream, false, true);
+}
 
 extern "C" int tq_cosmos_globals_grad(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "globals_grad")) return rc;
@@ -926,7 +1026,7 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
 
 extern "C" int64_t tq_cosmos_blk_floats(int32_t Nt, int32_t F, int32_t C, int32_t crosstalk, int64_t B) {
   const int64_t ncol = TQ_ROWS_GCOL + TQ_NGSUM_X(C, crosstalk);
-  const int64_t full = tq_cosmos_nblk((int64_t)Nt * F * C) * ncol;                           // full-batch rows of 256 units
+  const int64_t full = (((int64_t)Nt * F * C + 63) / 64) * ncol;                             // full-batch rows of 256 or 64 units
   const int64_t mini = ((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) * ncol;          // single-launch minibatch step: rows of 16
   const int64_t flat = tq_cosmos_nblk(B) * TQ_NGSUM_X(C, crosstalk);
   return full > mini ? (full > flat ? full : flat) : (mini > flat ? mini : flat);

@@ -160,16 +160,25 @@ __device__ __forceinline__ void tq_pixel_assemble_one_offset(const tq_ksmogn_arg
 template <int K, bool ONE_OFFSET, bool BWD>
 __device__ __forceinline__ void tq_pixel_store(const tq_ksmogn_args& a, int64_t B, int64_t i, const TqPixAcc<K>& A,
                                                const float* W, float b, float rg, const float* hk, const float* wk,
-                                               const float* cx, const float* cy, float fnpix, float S_v, bool bad) {
+                                               const float* cx, const float* cy, float fnpix, float S_v, bool bad,
+                                               float* OUT = nullptr) {
+  // OUT (registers of the caller: ll[M], g_background, g_gain, g_height[K], g_width[K], g_x[K], g_y[K] -- the row order
+  // of the step workspace `pix`) replaces the stores: the fused pixel + per-unit kernel consumes the values in place
   constexpr int M = 1 << K;
 #pragma unroll
-  for (int mi = 0; mi < M; ++mi) a.ll[(int64_t)mi * B + i] = bad ? -INFINITY : A.ll[mi];
+  for (int mi = 0; mi < M; ++mi) {
+    const float v = bad ? -INFINITY : A.ll[mi];
+    if (OUT) OUT[mi] = v;
+    else a.ll[(int64_t)mi * B + i] = v;
+  }
   if (BWD) {
     // a unit with a pixel at or below every offset has log p = -inf for every combination: no gradient
     // (selected, not multiplied: the sums of such a unit may hold inf / NaN)
     const bool dead = bad || A.ll[0] == -INFINITY;
     // d alpha = d mu / g for every mu-parameter
-    a.g_background[i] = dead ? 0.0f : A.acc_b * rg;
+    const float gb = dead ? 0.0f : A.acc_b * rg;
+    if (OUT) OUT[M] = gb;
+    else a.g_background[i] = gb;
     float acc_g = A.acc_g;
     if (ONE_OFFSET) {
       // sum_m W_m [alpha_m (da_m + 1) - v/g] = (1/g) [ sum_m W_m mu_m da_m + sum_m W_m mu_m - (sum_m W_m) v ]
@@ -187,17 +196,30 @@ __device__ __forceinline__ void tq_pixel_store(const tq_ksmogn_args& a, int64_t 
       }
       acc_g = rg * (mu_da + mu_w + Wsum * (b * fnpix - S_v));
     }
-    a.g_gain[i] = dead ? 0.0f : -acc_g * rg;
+    const float gg = dead ? 0.0f : -acc_g * rg;
+    if (OUT) OUT[M + 1] = gg;
+    else a.g_gain[i] = gg;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float rw = TQ_FRCP(wk[k]);
       const float S1x = A.Sx[k] - cx[k] * A.S0[k];
       const float S1y = A.Sy[k] - cy[k] * A.S0[k];
       const float S2 = A.Sr[k] - 2.0f * (cx[k] * A.Sx[k] + cy[k] * A.Sy[k]) + (cx[k] * cx[k] + cy[k] * cy[k]) * A.S0[k];
-      a.g_height[k * B + i] = dead ? 0.0f : A.S0[k] * rg * TQ_FRCP(hk[k]);
-      a.g_x[k * B + i] = dead ? 0.0f : rg * S1x * rw * rw;
-      a.g_y[k * B + i] = dead ? 0.0f : rg * S1y * rw * rw;
-      a.g_width[k * B + i] = dead ? 0.0f : rg * (S2 * rw * rw * rw - 2.0f * A.S0[k] * rw);
+      const float gh = dead ? 0.0f : A.S0[k] * rg * TQ_FRCP(hk[k]);
+      const float gx = dead ? 0.0f : rg * S1x * rw * rw;
+      const float gy = dead ? 0.0f : rg * S1y * rw * rw;
+      const float gw = dead ? 0.0f : rg * (S2 * rw * rw * rw - 2.0f * A.S0[k] * rw);
+      if (OUT) {
+        OUT[M + 2 + k] = gh;
+        OUT[M + 2 + K + k] = gw;
+        OUT[M + 2 + 2 * K + k] = gx;
+        OUT[M + 2 + 3 * K + k] = gy;
+      } else {
+        a.g_height[k * B + i] = gh;
+        a.g_x[k * B + i] = gx;
+        a.g_y[k * B + i] = gy;
+        a.g_width[k * B + i] = gw;
+      }
     }
   }
 }

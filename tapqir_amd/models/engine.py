@@ -120,6 +120,11 @@ class CosmosEngine:
         # form of the backward pixel kernel for contiguous batches (include/tapqir_hip.h: pixel_mode): None = not chosen
         # yet -> the first full-batch step times both forms on this box (autotune_pixel)
         self.pixel_mode = None
+        # full-batch single-GPU steps can run the pixel kernel and the per-unit kernel as ONE launch (pixel_mode =
+        # TQ_PIXEL_FUSED_UNIT of tq_cosmos_args): None = not chosen yet -> the first such step times both ways
+        # (autotune_fused); TAPQIR_AMD_FUSE_UNIT=0/1 fixes the choice
+        fu = os.environ.get("TAPQIR_AMD_FUSE_UNIT")
+        self.fuse_unit = None if fu is None else fu != "0"
         # minibatch steps with the lazy Adam clock run as ONE launch (include/tapqir_hip.h: tq_cosmos_minibatch_step);
         # TAPQIR_AMD_MB_FUSED=0 keeps the five-launch sequence
         self.fused_minibatch = self.pipelined_tail and os.environ.get("TAPQIR_AMD_MB_FUSED", "1") != "0"
@@ -429,6 +434,42 @@ class CosmosEngine:
         self.__dict__.pop("_tmpl_key", None)  # argument templates carry the mode
         return self.pixel_mode
 
+    def _fusable(self):
+        """Can a full-batch step of this engine run pixel + per-unit kernel in one launch?  (tq_cosmos.hip:
+        tq_fused_pixel_unit -- same conditions.)"""
+        return (self.pipelined_tail and not self.crosstalk and self.K <= 2 and self.O == 1 and self.P in (14, 20)
+                and self.Nt * self.F * self.C >= self.il_min_units and self.F * self.C >= 256
+                and os.environ.get("TAPQIR_AMD_ROWS", "1") != "0")
+
+    def autotune_fused(self, steps=4):
+        """Choose between two launches (pixel kernel, per-unit kernel) and the fused launch for the full-batch steps of
+        this box and dataset by timing ``steps`` real steps each way; parameters, optimiser state and step count are put
+        back afterwards."""
+        if not self._fusable():
+            self.fuse_unit = False
+            return False
+        self.join()
+        saved = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_step)
+        times = []
+        for fuse in (False, True):
+            self.fuse_unit = fuse
+            self.step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                self.step()
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) / steps)
+        self.join()
+        self.params.copy_(saved[0])
+        self.exp_avg.copy_(saved[1])
+        self.exp_avg_sq.copy_(saved[2])
+        self.adam_step = saved[3]
+        self.fuse_unit = bool(times[1] < times[0])
+        self.step_times_ms = times
+        return self.fuse_unit
+
     def step(self, ndx=None, fdx=None, allreduce=None):
         """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``).
 
@@ -439,6 +480,8 @@ class CosmosEngine:
         (called by every read-out) completes a deferred tail."""
         if self.pixel_mode is None and ndx is None and fdx is None and self.pipelined_tail:
             self.autotune_pixel()
+        if self.fuse_unit is None and ndx is None and fdx is None and allreduce is None and self.pipelined_tail:
+            self.autotune_fused()
         a = self._step_args(ndx, fdx)
         minibatch = bool(a.zero_grad)
         # Adam on the local block is fused into the unit kernel: full batches, and minibatches with the lazy clock
@@ -467,6 +510,8 @@ class CosmosEngine:
                 a.tail_kind = 1  # TQ_TAIL_ROWS16
                 self._tail_args = a
             elif self.overlap_tail and a.fuse_adam:
+                if self.fuse_unit and not minibatch and self._fusable():
+                    a.pixel_mode = 2  # TQ_PIXEL_FUSED_UNIT
                 prev = self._tail_args
                 _lib.check(self.lib.tq_cosmos_step_overlapped(C.byref(a), None if prev is None else C.byref(prev),
                                                               self._stream()), "tq_cosmos_step_overlapped")

@@ -243,3 +243,47 @@ def test_interleave_layout():
         for p in (0, 3, 4, 80):
             assert il[u // 64, p // 4, u % 64, p % 4] == img[u, p]
     assert eng.images_il.numel() == _lib.load().tq_interleaved_floats(U, 9)
+
+
+@pytest.mark.parametrize("K,P", [(2, 14), (1, 14), (2, 20)])
+def test_fused_pixel_unit_step_matches_the_two_launch_step(K, P):
+    """Full-batch steps with the pixel kernel and the per-unit kernel in ONE launch (pixel_mode = TQ_PIXEL_FUSED_UNIT: rows
+    of 64 units, pixel results handed over in registers) against the same steps as two launches (rows of 256 units,
+    oracle-checked above).  3 AOIs x 300 frames: 15 tiles, the last one with 4 live lanes, AOI boundaries inside tiles."""
+    d = make_dataset(N=3, F=300, K=K, P=P)
+    o = make_oracle(d, K, perturb=0.3)
+    engines = []
+    for fuse in (False, True):
+        eng = CosmosEngine(d, K=K, device="cuda:0", seed=11)
+        eng.il_min_units = 1
+        eng.pixel_mode, eng.fuse_unit = 0, fuse
+        oracle_to_engine(o, eng)
+        assert eng._fusable()
+        elbos = []
+        for it in range(4):
+            eng.step()
+            eng.join()
+            elbos.append(float(eng.elbo_out[0]))
+        torch.cuda.synchronize()
+        engines.append((eng, elbos))
+    (e0, l0), (e1, l1) = engines
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-6 * abs(a), (l0, l1)
+    p0, p1 = e0.named("params"), e1.named("params")
+    for n in p0:
+        assert (p0[n] - p1[n]).abs().max() < 2e-5, (n, float((p0[n] - p1[n]).abs().max()))
+    for buf in ("exp_avg", "exp_avg_sq"):
+        x, y = getattr(e0, buf), getattr(e1, buf)
+        assert torch.allclose(x, y, rtol=1e-3, atol=1e-6 * float(x.abs().max()))
+
+
+def test_autotune_fused_restores_the_state():
+    d = make_dataset(N=3, F=300, K=2)
+    o = make_oracle(d, 2, perturb=0.3)
+    eng = CosmosEngine(d, K=2, device="cuda:0", seed=11)
+    eng.il_min_units = 1
+    oracle_to_engine(o, eng)
+    before = (eng.params.clone(), eng.exp_avg.clone(), eng.adam_step)
+    chosen = eng.autotune_fused(steps=2)
+    assert chosen in (True, False) and len(eng.step_times_ms) == 2
+    assert torch.equal(eng.params, before[0]) and torch.equal(eng.exp_avg, before[1]) and eng.adam_step == before[2]
