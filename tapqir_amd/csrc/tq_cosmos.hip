@@ -445,6 +445,68 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   tq_globals_from_gsum_body(a, s_e);
 }
 
+// AOI-sharded full-batch steps: rows -> per-AOI sites and gsum (what the all-reduce needs), nothing of the global
+// sites.  One wave per (AOI, channel) adds the rows that overlap the AOI (a single workgroup would walk 400 AOIs x 17 rows
+// of 64 units in sequence, on the critical path of the step); the LAST workgroup to finish -- a device-scope ticket
+// after a release fence -- sums the rows and the per-AOI ELBO parts in fp64, in a fixed order.
+__global__ __launch_bounds__(256) void tq_rows_sums_kernel(const tq_cosmos_args a) {
+  __shared__ double s_w[4][TQ_MAX_NGSUM];
+  __shared__ int s_last;
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  const int64_t B = tq_batch_units(a);
+  const uint32_t UPR = (uint32_t)tq_rows_upr(a);
+  const int64_t nrows = (B + UPR - 1) / UPR;
+  const uint32_t FC = (uint32_t)(a.fb * a.C);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nac = a.nb * a.C;
+  const int ac = (int)blockIdx.x * 4 + wave;
+  if (ac < nac) {
+    const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;
+    const int c = ac - (int)ai * a.C;
+    const uint32_t r_lo = (ai * FC) / UPR, r_hi = ((ai + 1) * FC - 1) / UPR;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t r = r_lo + lane; r <= r_hi; r += 64) {
+      const int slot = (r * UPR) / FC == ai ? 0 : 1;
+      const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
+      s1 += row[0];
+      s2 += row[1];
+    }
+    s1 = tq_wave_sum(s1);
+    s2 = tq_wave_sum(s2);
+    if (lane == 0) {
+      float e;
+      tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
+      a.aoi_part[2 * B + ac] = e;  // (rows 0 and 1 of aoi_part belong to the flat layout; row 2 is scratch, nb*C <= B)
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&a.sync[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double acc[TQ_MAX_NGSUM];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
+  for (int64_t r = threadIdx.x; r < nrows; r += 256) {
+#pragma unroll
+    for (int j = 0; j < TQ_MAX_NGSUM; ++j)
+      if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_GCOL + j];
+  }
+  for (int r = threadIdx.x; r < nac; r += 256) acc[TQ_GS_ELBO] += (double)a.aoi_part[2 * B + r];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const double s = tq_wave_sum_d(acc[j]);
+      if (lane == 0) s_w[wave][j] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+  if (threadIdx.x == 0) __hip_atomic_store(&a.sync[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+}
+
 __global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_cosmos_args a, const int upr) {
   __shared__ double s_w[4][TQ_MAX_NGSUM];
   __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
@@ -845,6 +907,16 @@ static int launch_pixel_unit(const tq_cosmos_args* a, void* stream) {
   return check_launch("tq_pixel_unit_kernel");
 }
 
+// per-AOI sites + gsum of a step with rows, for callers that all-reduce gsum before the global sites (tq_rows_sums_kernel)
+static int launch_rows_sums(const tq_cosmos_args* a, hipStream_t st) {
+  if (!a->sync || !a->aoi_part || !a->gsum) {
+    tq_set_error("tq_cosmos_elbo_grads: the rows layout needs sync, aoi_part and gsum");
+    return TQ_ERR_ARG;
+  }
+  hipLaunchKernelGGL(tq_rows_sums_kernel, dim3((unsigned)((a->nb * a->C + 3) / 4)), dim3(256), 0, st, *a);
+  return check_launch("tq_rows_sums_kernel");
+}
+
 // rows: AOI-aligned per-unit kernel whose tail also finishes the per-AOI sites (tq_unit_rows_kernel; full-batch steps
 // that finish with tq_cosmos_tail or inside the next tq_cosmos_step_overlapped)
 static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_sums, bool rows = false) {
@@ -863,7 +935,8 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
                    "offset value, P in {14, 20}, the interleaved images and the pixel statistics");
       return TQ_ERR_ARG;
     }
-    return launch_pixel_unit(a, stream);
+    if (int rc = launch_pixel_unit(a, stream)) return rc;
+    return finish_sums ? launch_rows_sums(a, st) : TQ_OK;
   }
   // 1. pixel kernel
   if (int rc = launch_likelihood(a, stream)) return rc;
@@ -876,7 +949,8 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
       case 3: hipLaunchKernelGGL((tq_unit_rows_kernel<3>), grid, block, 0, st, *a, B); break;
       default: hipLaunchKernelGGL((tq_unit_rows_kernel<4>), grid, block, 0, st, *a, B); break;
     }
-    return check_launch("tq_unit_rows_kernel");
+    if (int rc = check_launch("tq_unit_rows_kernel")) return rc;
+    return finish_sums ? launch_rows_sums(a, st) : TQ_OK;
   }
   const int64_t nblk = tq_cosmos_nblk(B);
   const dim3 grid((unsigned)nblk), block(TQ_UNIT_BLOCK);
@@ -896,7 +970,11 @@ static int elbo_grads_impl(const tq_cosmos_args* a, void* stream, bool finish_su
   return check_launch("tq_reduce_kernel");
 }
 
-extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) { return elbo_grads_impl(a, stream, true); }
+extern "C" int tq_cosmos_elbo_grads(const tq_cosmos_args* a, void* stream) {
+  // full-batch steps with the Adam of the local parameters fused in take the rows layout here too (the per-AOI sites are
+  // finished by tq_rows_sums_kernel, which also leaves gsum ready for the caller's all-reduce)
+  return elbo_grads_impl(a, stream, true, a && tq_rows_layout(*a) && a->sync && a->aoi_part);
+}
 
 extern "C" int tq_cosmos_pixel_unit(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "pixel_unit")) return rc;

@@ -543,6 +543,8 @@ class CosmosEngine:
                     self._finish_pending(next_args=a)  # ... and draws this step's global sites in the same launch
                 else:
                     self.call("cosmos_sample_globals", a)
+            if a.fuse_adam and not minibatch and self.fuse_unit is not False and self._fusable():
+                a.pixel_mode = 2  # TQ_PIXEL_FUSED_UNIT (not timed against the two-launch form on this path)
             self.call("cosmos_elbo_grads", a)
             handle = allreduce(self.gsum) if allreduce is not None else None
             if handle is not None and hasattr(handle, "wait") and a.fuse_adam:

@@ -287,3 +287,40 @@ def test_autotune_fused_restores_the_state():
     chosen = eng.autotune_fused(steps=2)
     assert chosen in (True, False) and len(eng.step_times_ms) == 2
     assert torch.equal(eng.params, before[0]) and torch.equal(eng.exp_avg, before[1]) and eng.adam_step == before[2]
+
+
+@pytest.mark.parametrize("handle", [False, True], ids=["blocking", "in_flight"])
+@pytest.mark.parametrize("fuse", [False, True], ids=["two_launches", "fused"])
+def test_sharded_launch_sequence_with_rows_matches_the_pipelined_step(handle, fuse):
+    """The launch sequence of an AOI-sharded full-batch step (tq_cosmos_elbo_grads with the rows layout -- per-AOI sites and
+    gsum finished by tq_rows_sums_kernel -- then the all-reduce, here of one rank, then tq_cosmos_tail_reduced inside the
+    next step's split sampling) against the pipelined single-GPU step on the same data."""
+
+    class Done:
+        def wait(self):
+            pass
+
+    d = make_dataset(N=3, F=300, K=2)
+    o = make_oracle(d, 2, perturb=0.3)
+    results = []
+    for sharded in (False, True):
+        eng = CosmosEngine(d, K=2, device="cuda:0", seed=11)
+        eng.il_min_units = 1
+        eng.pixel_mode, eng.fuse_unit = 0, fuse
+        oracle_to_engine(o, eng)
+        elbos = []
+        for it in range(4):
+            if sharded:
+                eng.step(allreduce=(lambda g: Done()) if handle else (lambda g: None))
+            else:
+                eng.step()
+            eng.join()
+            elbos.append(float(eng.elbo_out[0]))
+        torch.cuda.synchronize()
+        results.append((eng, elbos))
+    (e0, l0), (e1, l1) = results
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-6 * abs(a), (l0, l1)
+    p0, p1 = e0.named("params"), e1.named("params")
+    for n in p0:
+        assert (p0[n] - p1[n]).abs().max() < 2e-5, (n, float((p0[n] - p1[n]).abs().max()))
