@@ -133,7 +133,11 @@ TQ_HD void tq_gamma_site_terms(float v, float loc, float beta, float* s) {
   s[1] = d_v;
   s[2] = d_alpha;
   s[3] = d_beta;
+#ifdef TQ_DIAG_NO_GAMMAGRAD  // (diagnostic builds: scripts/gpu_site_diag.sh)
+  s[4] = v;
+#else
   s[4] = tq_std_gamma_grad(loc * beta, v * beta) * TQ_FRCP(beta);
+#endif
   s[5] = 0.0f;
 }
 
@@ -144,7 +148,11 @@ TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low,
   const float c1 = size * (mean - low) * rsc;
   const float c0 = size * (high - mean) * rsc;
   float lq, d_t, d_c1, d_c0;
+#ifdef TQ_DIAG_NO_BETALP
+  lq = t; d_t = c1; d_c1 = c0; d_c0 = t;
+#else
   tq_beta_logpdf(t, c1, c0, &lq, &d_t, &d_c1, &d_c0);
+#endif
   s[0] = lq - TQ_FLOG(sc);
   s[1] = d_t * rsc;
   s[2] = d_c1;
@@ -152,7 +160,11 @@ TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low,
   // pathwise: y = low + sc * t unless clamped by rsample
   const bool clamped = (y <= low + eps * sc) || (y >= high - eps * sc);
   float dd[2] = {0.0f, 0.0f};
+#ifdef TQ_DIAG_NO_BETAGRAD
+  if (false) {
+#else
   if (!clamped) {
+#endif
     double ga, gb;
     if (tq_beta_grad_pair_mid((double)t, (double)c1, (double)size - (double)c1, &ga, &gb)) {
       dd[0] = (float)ga;  // common case: both directions in the saddle-point regime, evaluated together
