@@ -23,6 +23,10 @@ done
 unset TAPQIR_AMD_PERSIST
 cd $R
 python3 scripts/make_pmc_traffic.py $O/pmc_traffic.json 2 14 400000 $O/pmc_summary_form0.txt $O/pmc_summary_form1.txt > /dev/null
+# 2b. PMC passes over the step itself (every kernel of a c2 step, fused pixel + per-unit launch included)
+STEPOUT=steppmc bash $R/scripts/gpu_step_pmc.sh > $O/steppmc.log 2>&1
+cp $R/gpurun_out/steppmc/summary.txt $O/pmc_summary_step.txt
+cd $R
 # 3. bench lines
 timeout -k 10 400 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "c2 rc=$?"
 timeout -k 10 300 python3 bench.py --config c3 --no-cpu --trained-steps 0 > $O/bench_c3shard.json 2>/dev/null; echo "c3 rc=$?"
