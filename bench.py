@@ -339,16 +339,27 @@ def time_fused_kernel(eng, launches):
     eng.call("cosmos_sample_locals", a)
     for _ in range(2):
         eng.call("cosmos_pixel_unit", a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(launches):
-        eng.call("cosmos_pixel_unit", a)
-    e1.record()
-    e1.synchronize()
+    # As in a step, the local sampling launch runs between two launches of this kernel (back to back with itself the
+    # kernel also waits for its predecessor's 86 MB of parameter writes to drain).  Timed as the difference between
+    # `launches` x (sampling, this kernel) and `launches` x sampling, each as one uninterrupted sequence: an event
+    # between two launches would add the dispatch latency that queued launches hide.
+    def sequence(with_kernel):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            eng.call("cosmos_sample_locals", a)
+            if with_kernel:
+                eng.call("cosmos_pixel_unit", a)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    sequence(True)
+    total_ms = sequence(True) - sequence(False)
     eng.params.copy_(saved[0])
     eng.exp_avg.copy_(saved[1])
     eng.exp_avg_sq.copy_(saved[2])
-    return e0.elapsed_time(e1) / launches * 1e-3
+    return total_ms / launches * 1e-3
 
 
 def roofline_block(pb, ms_per_step, dev):

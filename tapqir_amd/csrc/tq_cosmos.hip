@@ -1045,6 +1045,12 @@ static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
 
 extern "C" int tq_cosmos_tail(const tq_cosmos_args* a, void* stream) {
   if (int rc = check_args(a, "tail")) return rc;
+  if (a->tail_kind != TQ_TAIL_ROWS16 && tq_rows_layout(*a) && a->fuse_adam && a->sync && a->aoi_part) {
+    // rows of 64 or 256 units: the per-AOI frame sums span up to F C / 64 rows each -- one wave per AOI
+    // (tq_rows_sums_kernel) instead of one workgroup walking all of them, then the global sites + tail Adam
+    if (int rc = launch_rows_sums(a, (hipStream_t)stream)) return rc;
+    return tq_cosmos_tail_reduced(a, nullptr, stream);
+  }
   if (int rc = launch_reduce_globals(a, (hipStream_t)stream)) return rc;
   return tq_cosmos_adam(a, stream);
 }
