@@ -28,5 +28,6 @@ if os.environ.get("STAMPS"):
     print("ticket barrier %.1f us, to phase-1 start %.1f us" % ((int(st[6]) - int(st[0])) / 100.0, (int(st[7]) - int(st[0])) / 100.0))
     d = [(int(st[i + 1]) - int(st[i])) / 100.0 for i in range(5)]
     print("stamps (us): catchup %.1f  sites %.1f  wait %.1f  pixel %.1f  unit %.1f  total %.1f" % (*d, (int(st[5]) - int(st[0])) / 100.0))
+    print("  inside the tail: per-AOI sums done %.1f, cross-unit sums (gsum) done %.1f" % ((int(st[13]) - int(st[0])) / 100.0, (int(st[12]) - int(st[0])) / 100.0))
     t = [(int(st[i]) - int(st[0])) / 100.0 for i in (8, 9, 10, 11)]
     print("tail workgroup (us since stamp 0 of block %s): start %.1f  sums+global grads done %.1f  adam done %.1f  flag %.1f" % (os.environ.get("STAMPS"), *t))

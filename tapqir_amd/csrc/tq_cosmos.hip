@@ -409,6 +409,9 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
         acc[TQ_GS_ELBO] += (double)e;
       }
     }
+#ifdef TQ_MB_STAMPS
+    if (threadIdx.x == 0) ((uint64_t*)(a.sync + 4))[13] = __builtin_amdgcn_s_memrealtime();
+#endif
   } else {
     for (int ac = threadIdx.x; ac < nac; ac += 256) {
       const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;  // position of the AOI in the batch
@@ -442,6 +445,9 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
   __threadfence_block();
   __syncthreads();
+#ifdef TQ_MB_STAMPS
+  if (UPR_T == 16 && threadIdx.x == 0) ((uint64_t*)(a.sync + 4))[12] = __builtin_amdgcn_s_memrealtime();
+#endif
   tq_globals_from_gsum_body(a, s_e);
 }
 

@@ -293,7 +293,11 @@ class Model:
             # first file of a run(): written here, while the helper process for the following ones starts
             from tapqir_amd.utils.ckpt_writer import CheckpointWriter
 
-            self._ckpt_process = CheckpointWriter(eng.params.numel(), eng.params.device)
+            try:
+                self._ckpt_process = CheckpointWriter(eng.params.numel(), eng.params.device)
+            except Exception as err:  # no /dev/shm, no child process: every file is written in-process
+                logger.warning(f"checkpoint helper process not available ({err!r}); writing checkpoints in-process")
+                os.environ["TAPQIR_AMD_CKPT_PROCESS"] = "0"
         self._join_checkpoint_writer()
         from tapqir_amd.utils.ckpt_writer import write_file
 
