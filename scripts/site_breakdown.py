@@ -23,7 +23,8 @@ data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
 eng = CosmosEngine(data, K=2, device=dev, seed=7)
 eng.layout.set_constrained(eng.params, initial_values(eng, data))
 names = ["b"] + [f"{s}{k}" for s in "hwxy" for k in range(2)]  # site order of `lat`
-for phase, nsteps in (("init", 0), ("after 300 steps", 300)):
+NSTEPS = int(os.environ.get("STEPS", 300))
+for phase, nsteps in (("init", 0), (f"after {NSTEPS} steps", NSTEPS)):
     for _ in range(nsteps):
         eng.step()
     eng.join()

@@ -545,12 +545,16 @@ TQ_HD float tq_beta_grad_window_f(float x, float alpha, float beta) {
   return prefactor_num * poly * TQ_FRCP(prefactor_den);
 }
 
+// ANY_BOUNDARY: the saddle-point formulas for alpha, beta > 6 whatever total x (1-x) is -- for a draw near an edge
+// only ONE of the two directions is in the saddle-point regime (the other one is in a series regime); the caller
+// keeps the direction it needs (tq_beta_grad_pair_rest).
+template <bool ANY_BOUNDARY = false>
 TQ_HD bool tq_beta_grad_pair_mid(double x, double alpha, double beta, double* ga, double* gb) {
   const double total = alpha + beta;
   const double y = 1.0 - x;
   const double xy = x * y;
   const double boundary = total * xy;
-  if (!(boundary >= 2.5 && alpha > 6.0 && beta > 6.0)) return false;
+  if (!((ANY_BOUNDARY || boundary >= 2.5) && alpha > 6.0 && beta > 6.0)) return false;
   // ONE reciprocal, of alpha beta total x y, gives 1/total, 1/x, 1/y, 1/alpha, 1/beta by multiplication (a Newton
   // reciprocal in double is ~7 instructions; this routine is a third of the local sampling kernel)
   const double P = alpha * beta;
@@ -611,13 +615,10 @@ TQ_HD bool tq_beta_grad_pair_mid(double x, double alpha, double beta, double* ga
   return true;
 }
 
-TQ_HD_NOINLINE float tq_dirichlet_grad(float x_, float alpha_, float total_) {
+// rational regime of torch's _dirichlet_grad (neither series regime, alpha or beta <= 6)
+TQ_HD float tq_beta_grad_rational(float x_, float alpha_, float total_) {
   const double x = x_, alpha = alpha_, total = total_;
   const double beta = total - alpha;
-  const double boundary = total * x * (1.0 - x);
-  if (x <= 0.5 && boundary < 2.5) return (float)tq_beta_grad_alpha_small(x, alpha, beta);
-  if (x >= 0.5 && boundary < 0.75) return -tq_beta_grad_beta_small_f(1.0f - x_, total_ - alpha_, alpha_);
-  if (alpha > 6.0 && beta > 6.0) return (float)tq_beta_grad_alpha_mid(x, alpha, beta);
   // rational correction to an analytic approximation; coefficients: PyTorch (BSD-3)
   const float c[2][3][3][4] = {
       {{{1.003668233f, -0.01061107488f, -0.0657888334f, 0.01201642863f},
@@ -654,4 +655,76 @@ TQ_HD_NOINLINE float tq_dirichlet_grad(float x_, float alpha_, float total_) {
     }
   const double approx = x * (tq_digamma_fast_d(total) - tq_digamma_fast_d(alpha)) * tq_drcp(beta);
   return p * TQ_FRCP(q) * (float)approx;
+}
+
+TQ_HD int tq_dirichlet_grad_regime(double x, double alpha, double beta, double total) {
+  const double boundary = total * x * (1.0 - x);
+  if (x <= 0.5 && boundary < 2.5) return 0;     // x-small series (fp64)
+  if (x >= 0.5 && boundary < 0.75) return 1;    // (1-x)-small series
+  if (alpha > 6.0 && beta > 6.0) return 2;      // saddle point
+  return 3;                                     // rational
+}
+
+TQ_HD_NOINLINE float tq_dirichlet_grad(float x_, float alpha_, float total_) {
+  const double x = x_, alpha = alpha_, total = total_;
+  const double beta = total - alpha;
+  const int regime = tq_dirichlet_grad_regime(x, alpha, beta, total);
+  if (regime == 0) return (float)tq_beta_grad_alpha_small(x, alpha, beta);
+  if (regime == 1) return -tq_beta_grad_beta_small_f(1.0f - x_, total_ - alpha_, alpha_);
+  if (regime == 2) return (float)tq_beta_grad_alpha_mid(x, alpha, beta);
+  return tq_beta_grad_rational(x_, alpha_, total_);
+}
+
+// Both directions of one Beta draw, dd[0] = tq_dirichlet_grad(t, c1, size), dd[1] = tq_dirichlet_grad(1 - t, c0, size),
+// when tq_beta_grad_pair_mid does not apply -- what the two calls return (bit for bit in the series and rational regimes;
+// a direction in the saddle-point regime comes from the pair routine, same formulas, rounding-level differences), but
+// arranged by REGIME instead of by direction.  Lanes of a wave fall into all regimes once a fit has converged (absent spots: size 5..20, present
+// ones several hundred), and a wave executes every branch some lane takes: called twice, each of the three expensive
+// regimes ran twice per wave.  The two directions of a lane never share the x-small series (x <= 1/2 for one means
+// 1 - x >= 1/2 for the other), the (1-x)-small series or -- outside the pair routine -- the saddle point, so each of
+// series runs ONCE with per-lane arguments from whichever direction needs it; only the (float) rational regime can be
+// needed by both.
+TQ_HD_NOINLINE void tq_beta_grad_pair_rest(float t, float c1, float c0, float size, float* dd) {
+  const float xf[2] = {t, 1.0f - t};
+  const float af[2] = {c1, c0};
+  const double total = size;
+  int regime[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) regime[j] = tq_dirichlet_grad_regime((double)xf[j], (double)af[j], total - (double)af[j], total);
+  dd[0] = dd[1] = 0.0f;
+  // saddle-point regime of ONE direction (both: tq_beta_grad_pair_mid has returned true and this routine is not
+  // called): the pair routine once, keeping the direction(s) that asked for it
+  if (regime[0] == 2 || regime[1] == 2) {
+    double ga = 0.0, gb = 0.0;
+    if (tq_beta_grad_pair_mid<true>((double)t, (double)c1, total - (double)c1, &ga, &gb)) {
+      if (regime[0] == 2) dd[0] = (float)ga;
+      if (regime[1] == 2) dd[1] = (float)gb;
+    } else {  // (the two directions disagree about alpha, beta > 6 within rounding: the plain evaluation)
+#pragma nounroll
+      for (int j = 0; j < 2; ++j)
+        if (regime[j] == 2) dd[j] = (float)tq_beta_grad_alpha_mid((double)xf[j], (double)af[j], total - (double)af[j]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const bool n0 = regime[0] == r, n1 = regime[1] == r;
+    // pass 0: every lane that needs regime r evaluates ONE direction (the first if both do); pass 1: the second
+    // direction of lanes that need it for both (x = 1/2 exactly) -- a run-time loop, so the regime's code exists once
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool act = pass == 0 ? (n0 || n1) : (n0 && n1);
+      if (act) {
+        const bool first = pass == 0 && n0;
+        const float xs = first ? xf[0] : xf[1], as = first ? af[0] : af[1];
+        float g;
+        if (r == 0) g = (float)tq_beta_grad_alpha_small((double)xs, (double)as, total - (double)as);
+        else g = -tq_beta_grad_beta_small_f(1.0f - xs, size - as, as);
+        if (first) dd[0] = g;
+        else dd[1] = g;
+      }
+    }
+  }
+#pragma nounroll
+  for (int j = 0; j < 2; ++j)
+    if (regime[j] == 3) dd[j] = tq_beta_grad_rational(xf[j], af[j], size);
 }

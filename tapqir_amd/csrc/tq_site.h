@@ -170,9 +170,7 @@ TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low,
       dd[0] = (float)ga;  // common case: both directions in the saddle-point regime, evaluated together
       dd[1] = (float)gb;
     } else {
-      // the two implicit gradients share one (not unrolled) loop so the fp64 code is emitted once
-#pragma nounroll
-      for (int j = 0; j < 2; ++j) dd[j] = tq_dirichlet_grad(j ? 1.0f - t : t, j ? c0 : c1, size);
+      tq_beta_grad_pair_rest(t, c1, c0, size, dd);  // the other regimes, each run once for both directions
     }
   }
   s[4] = sc * dd[0] * (1.0f - t);

@@ -35,6 +35,18 @@ void hc_beta_grad_pair(const float* x, const float* c1, const float* c0, float* 
     else { ga[i] = tq_dirichlet_grad(x[i], c1[i], total); gb[i] = tq_dirichlet_grad(1.0f - x[i], c0[i], total); }
   }
 }
+// the regime-ordered evaluation of both directions (tq_beta_grad_pair_rest) next to the two plain calls it replaces
+void hc_beta_grad_pair_rest(const float* x, const float* c1, const float* c0, float* ga, float* gb, float* ra, float* rb, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    const float total = c1[i] + c0[i];
+    float dd[2];
+    tq_beta_grad_pair_rest(x[i], c1[i], c0[i], total, dd);
+    ga[i] = dd[0];
+    gb[i] = dd[1];
+    ra[i] = tq_dirichlet_grad(x[i], c1[i], total);
+    rb[i] = tq_dirichlet_grad(1.0f - x[i], c0[i], total);
+  }
+}
 void hc_sample_std_gamma(uint64_t seed, uint32_t step, uint32_t site, const float* alpha, float* out, int64_t n) {
   for (int64_t i = 0; i < n; ++i) {
     TqPhilox s;

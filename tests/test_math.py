@@ -131,3 +131,26 @@ def test_fused_beta_gradient_pair_matches_torch():
     ref_b = torch._dirichlet_grad((1 - torch.tensor(x32)).double(), T - A, T).numpy()
     assert np.all(np.abs(ga - ref_a) <= 1e-4 * np.abs(ref_a) + 1e-12)
     assert np.all(np.abs(gb - ref_b) <= 1e-4 * np.abs(ref_b) + 1e-12)
+
+
+def test_regime_ordered_beta_gradient_pair_is_the_two_plain_calls():
+    """tq_beta_grad_pair_rest evaluates both directions of a Beta draw regime by regime (each expensive regime once per
+    wave instead of once per direction); its results are those of the two tq_dirichlet_grad calls."""
+    hc = load_hostcheck()
+    g = torch.Generator().manual_seed(4)
+    n = 60000
+    c1 = 10 ** (torch.rand(n, generator=g) * 3.3 - 0.3)  # 0.5 .. 1000: every regime of the piecewise scheme
+    c0 = 10 ** (torch.rand(n, generator=g) * 3.3 - 0.3)
+    torch.manual_seed(3)
+    x = torch.distributions.Beta(c1.double(), c0.double()).sample().clamp(1e-6, 1 - 1e-6)
+    x[:200] = 0.5  # both directions in the same series regime
+    x32, a32, b32 = _f32(x.numpy()), _f32(c1.numpy()), _f32(c0.numpy())
+    out = [np.empty_like(x32) for _ in range(4)]
+    hc.hc_beta_grad_pair_rest(_p(x32), _p(a32), _p(b32), *[_p(o) for o in out], C.c_int64(x32.size))
+    ga, gb, ra, rb = out
+    assert np.isfinite(ga).all() and np.isfinite(gb).all()
+    # series and rational regimes: the same code on the same arguments; a direction in the saddle-point regime comes from
+    # the pair routine (same formulas, one reciprocal for five): rounding-level differences
+    same = (ga.view(np.uint32) == ra.view(np.uint32)) & (gb.view(np.uint32) == rb.view(np.uint32))
+    assert same.mean() > 0.5
+    assert np.all(np.abs(ga - ra) <= 5e-6 * np.abs(ra)) and np.all(np.abs(gb - rb) <= 5e-6 * np.abs(rb))
