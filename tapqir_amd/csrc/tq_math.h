@@ -421,12 +421,21 @@ TQ_HD float tq_digamma_f(float a) {
   return TQ_FLOG(a) - 0.5f * ra - r2 * (1.0f / 12.0f - r2 * (1.0f / 120.0f - r2 * (1.0f / 252.0f))) - shift;
 }
 
+// psi(total) - psi(alpha) for total > alpha > 0.  In float when the difference is not a small one of two large values
+// (total >= 1.1 alpha: absolute error ~3e-7 of each digamma against a difference >= 0.09 -- relative error ~1e-5, far
+// inside what torch's own float32 evaluation has); in double otherwise.  Fits that have converged sit almost entirely in the
+// first case (c1 ~ c0), and the double branch with its reciprocal loops is then skipped by whole waves.
+TQ_HD float tq_digamma_diff(float total, float alpha) {
+  if (total >= 1.1f * alpha) return tq_digamma_f(total) - tq_digamma_f(alpha);
+  return (float)(tq_digamma_fast_d((double)total) - tq_digamma_fast_d((double)alpha));
+}
+
 // The 1-x-small series regime of torch's _dirichlet_grad in fp32 (terms decay like (1-x)^i / i!; checked against
 // the fp64 evaluation to 5e-5).  The x-small regime stays in fp64: its alternating series cancels by factors of
 // several hundred when beta x is near the regime boundary and needs psi, ln x and 1/(alpha+i) to ~1e-9.
 TQ_HD float tq_beta_grad_beta_small_f(float x, float alpha, float beta) {
-  // psi(alpha + beta) - psi(beta) cancels when alpha << beta: the two digammas in fp64
-  const float factor = (float)(tq_digamma_fast_d((double)alpha + (double)beta) - tq_digamma_fast_d((double)beta));
+  // psi(alpha + beta) - psi(beta) cancels when alpha << beta: then the two digammas in fp64 (tq_digamma_diff)
+  const float factor = tq_digamma_diff(alpha + beta, beta);
   float numer = 1.0f, betas = 1.0f, dbetas = 0.0f, series = factor * TQ_FRCP(alpha);
 #pragma nounroll
   for (int i = 1; i <= 8; ++i) {
@@ -640,7 +649,7 @@ TQ_HD float tq_beta_grad_rational(float x_, float alpha_, float total_) {
         {0.001925008108f, -0.002869809258f, 0.0008000589141f, -6.063713228e-05f},
         {-0.0003477407336f, 6.959756487e-05f, 1.097287507e-05f, -1.650964693e-06f}}},
   };
-  // the O(1) rational correction in fp32 (as torch does for float32 tensors); the digamma difference below in fp64
+  // the O(1) rational correction in fp32 (as torch does for float32 tensors); the digamma difference: tq_digamma_diff
   const float u = TQ_FLOG(x_);
   const float a = TQ_FLOG(alpha_) - u;
   const float b = TQ_FLOG(total_) - a;
@@ -653,8 +662,8 @@ TQ_HD float tq_beta_grad_rational(float x_, float alpha_, float total_) {
       p += ua * (c[0][i][j][0] + b * (c[0][i][j][1] + b * (c[0][i][j][2] + b * c[0][i][j][3])));
       q += ua * (c[1][i][j][0] + b * (c[1][i][j][1] + b * (c[1][i][j][2] + b * c[1][i][j][3])));
     }
-  const double approx = x * (tq_digamma_fast_d(total) - tq_digamma_fast_d(alpha)) * tq_drcp(beta);
-  return p * TQ_FRCP(q) * (float)approx;
+  const float approx = x_ * tq_digamma_diff(total_, alpha_) * TQ_FRCP((float)beta);
+  return p * TQ_FRCP(q) * approx;
 }
 
 TQ_HD int tq_dirichlet_grad_regime(double x, double alpha, double beta, double total) {
@@ -694,7 +703,11 @@ TQ_HD_NOINLINE void tq_beta_grad_pair_rest(float t, float c1, float c0, float si
   dd[0] = dd[1] = 0.0f;
   // saddle-point regime of ONE direction (both: tq_beta_grad_pair_mid has returned true and this routine is not
   // called): the pair routine once, keeping the direction(s) that asked for it
+#if defined(TQ_DIAG_NO_R2)
+  if (false) {
+#else
   if (regime[0] == 2 || regime[1] == 2) {
+#endif
     double ga = 0.0, gb = 0.0;
     if (tq_beta_grad_pair_mid<true>((double)t, (double)c1, total - (double)c1, &ga, &gb)) {
       if (regime[0] == 2) dd[0] = (float)ga;
@@ -717,8 +730,16 @@ TQ_HD_NOINLINE void tq_beta_grad_pair_rest(float t, float c1, float c0, float si
         const bool first = pass == 0 && n0;
         const float xs = first ? xf[0] : xf[1], as = first ? af[0] : af[1];
         float g;
+#if defined(TQ_DIAG_NO_R0)  // (diagnostic builds: scripts/gpu_site_diag.sh)
+        if (r == 0) g = xs;
+#else
         if (r == 0) g = (float)tq_beta_grad_alpha_small((double)xs, (double)as, total - (double)as);
+#endif
+#if defined(TQ_DIAG_NO_R1)
+        else g = as;
+#else
         else g = -tq_beta_grad_beta_small_f(1.0f - xs, size - as, as);
+#endif
         if (first) dd[0] = g;
         else dd[1] = g;
       }
@@ -726,5 +747,9 @@ TQ_HD_NOINLINE void tq_beta_grad_pair_rest(float t, float c1, float c0, float si
   }
 #pragma nounroll
   for (int j = 0; j < 2; ++j)
+#if defined(TQ_DIAG_NO_R3)
+    if (regime[j] == 3) dd[j] = xf[j];
+#else
     if (regime[j] == 3) dd[j] = tq_beta_grad_rational(xf[j], af[j], size);
+#endif
 }
