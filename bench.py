@@ -79,6 +79,28 @@ def pmc_traffic(K, P, units, backward):
     return None, None
 
 
+def pmc_valu_issue(kernel_tag, units, avg_launch_s):
+    """VALU issue figures of the dominant kernel from the committed PMC passes (profiles/*_pmc_valu.json; separate
+    rocprofv3 --pmc runs, scripts/gpu_step_pmc.sh): the kernels whose HBM fraction is low are bound by instruction issue,
+    and this is the roof they are at.  `busy_at_nominal_clock` prices the measured launch of THIS run at 2.4 GHz."""
+    prof = os.path.join(ROOT, "profiles")
+    for name in ("r02_pmc_valu.json",):
+        try:
+            d = json.load(open(os.path.join(prof, name)))
+        except OSError:
+            continue
+        c = d["configs"].get(kernel_tag)
+        if c and c["units"] == units:
+            cycles_per_simd = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024
+            return {"bound": "valu_issue", "source": f"profiles/{name}", "kernel": c["kernel"],
+                    "valu_instructions_per_launch": c["SQ_INSTS_VALU"], "of_which_transcendental": c["SQ_INSTS_VALU_TRANS_F32"],
+                    "issue_cycles_per_simd": cycles_per_simd, "busy_in_profiled_launch": c["valu_busy"],
+                    "busy_at_nominal_clock": cycles_per_simd / (avg_launch_s * 2.4e9),
+                    "note": "fraction of the launch during which a SIMD issues a VALU instruction (SQ_ACTIVE_INST_VALU x 4 / 1024 "
+                            "SIMDs over the launch's cycles); 1.0 is the roof of an issue-bound kernel"}
+    return None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # parent: start one process per GPU.  Nothing in this function (or before it in main) touches the GPU.
 # ---------------------------------------------------------------------------------------------------------------------
@@ -405,6 +427,10 @@ def roofline_block(pb, ms_per_step, dev):
                                         f"this box: {[round(t, 4) for t in getattr(eng, 'step_times_ms', [])]} ms per step)",
                               "bytes_per_unit": sb, "units_per_launch": tot_units, "avg_launch_ms": t_pu * 1e3,
                               "achieved": tot_units * sb / t_pu / 1e9, "frac": tot_units * sb / t_pu / 1e9 / HBM_PEAK_GBS}
+    tag = "c4" if eng.crosstalk else ("hist" if eng.O > 1 else ("c5" if (K, P) == (3, 20) else ("c2" if (K, P) == (2, 14) else None)))
+    vi = pmc_valu_issue(tag, units, t_fb) if tag else None
+    if vi:
+        out["valu_issue"] = vi
     if eng.O > 1:
         # the offset-histogram kernel is bound by the transcendental pipe, not by HBM: (K+1) + 1 exp2/log2 per
         # (offset, pixel); peak = v_exp_f32 issue rate of profiles/r01_valu_issue_rates.txt (8 cycles per wave64) x 1024 SIMDs
