@@ -362,6 +362,28 @@ static bool tq_fused_pixel_unit(const tq_cosmos_args& a) {
 }
 static int launch_pixel_unit(const tq_cosmos_args* a, void* stream);
 
+// acc[j] += sum over this thread's rows (r = threadIdx.x, + 256, ...) of column j of the cross-unit sums.  Four rows are
+// REQUESTED before any is added: with one row in flight at a time the 25 rows per thread of a c2-sized step with rows of
+// 64 units were 25 memory latencies in sequence (~25 us, which made the tail workgroup the last one of the sampling
+// launch it hides in).  Same order of additions per thread as the plain loop.
+__device__ __forceinline__ void tq_rows_column_sums(const tq_cosmos_args& a, int64_t nrows, int nq, int ncol, double* acc) {
+  for (int64_t r0 = threadIdx.x; r0 < nrows; r0 += 4 * 256) {
+    float v[4][TQ_MAX_NGSUM];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + 256 * u;
+#pragma unroll
+      for (int j = 0; j < TQ_MAX_NGSUM; ++j) v[u][j] = (r < nrows && j < nq) ? a.blk_part[r * ncol + TQ_ROWS_GCOL + j] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < TQ_MAX_NGSUM; ++j)
+        if (j < nq) acc[j] += (double)v[u][j];
+    }
+  }
+}
+
 // Tail of a step whose per-unit kernel wrote such rows (ONE workgroup of 256 threads): per-AOI sites from the rows that
 // overlap the AOI, cross-unit sums in fp64, global sites and the total ELBO.
 // UPR = units per row: TQ_UNIT_BLOCK (tq_unit_rows_kernel) or 16 (the single-launch minibatch step)
@@ -418,21 +440,35 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
       const int c = ac - (int)ai * a.C;
       const uint32_t r_lo = (ai * FC) / UPR, r_hi = ((ai + 1) * FC - 1) / UPR;
       float s1 = 0.0f, s2 = 0.0f;
-      for (uint32_t r = r_lo; r <= r_hi; ++r) {
-        const int slot = (r * UPR) / FC == ai ? 0 : 1;
-        const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
-        s1 += row[0];
-        s2 += row[1];
+      for (uint32_t rb = r_lo; rb <= r_hi; rb += 4) {  // four rows requested before any is added (see tq_rows_column_sums)
+        float p1[4], p2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t r = rb + u;
+          const int slot = (r * UPR) / FC == ai ? 0 : 1;
+          const float* row = a.blk_part + (int64_t)r * ncol + slot * TQ_ROWS_AOICOL + 2 * c;
+          p1[u] = r <= r_hi ? row[0] : 0.0f;
+          p2[u] = r <= r_hi ? row[1] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s1 += p1[u];
+          s2 += p2[u];
+        }
       }
       float e;
       tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
       acc[TQ_GS_ELBO] += (double)e;
     }
   }
-  for (int64_t r = threadIdx.x; r < nrows; r += 256) {
+  if constexpr (UPR_T == 16) {  // a few hundred rows: the plain loop (and no extra registers in the minibatch kernel)
+    for (int64_t r = threadIdx.x; r < nrows; r += 256) {
 #pragma unroll
-    for (int j = 0; j < TQ_MAX_NGSUM; ++j)
-      if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_GCOL + j];
+      for (int j = 0; j < TQ_MAX_NGSUM; ++j)
+        if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_GCOL + j];
+    }
+  } else {
+    tq_rows_column_sums(a, nrows, nq, ncol, acc);
   }
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
@@ -495,11 +531,7 @@ __global__ __launch_bounds__(256) void tq_rows_sums_kernel(const tq_cosmos_args 
   double acc[TQ_MAX_NGSUM];
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
-  for (int64_t r = threadIdx.x; r < nrows; r += 256) {
-#pragma unroll
-    for (int j = 0; j < TQ_MAX_NGSUM; ++j)
-      if (j < nq) acc[j] += (double)a.blk_part[r * ncol + TQ_ROWS_GCOL + j];
-  }
+  tq_rows_column_sums(a, nrows, nq, ncol, acc);
   for (int r = threadIdx.x; r < nac; r += 256) acc[TQ_GS_ELBO] += (double)a.aoi_part[2 * B + r];
 #pragma unroll
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
