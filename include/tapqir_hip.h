@@ -252,7 +252,10 @@ typedef struct {
                                   _step_overlapped / _elbo_grads wrote) or TQ_TAIL_ROWS16 (the step ran as
                                   tq_cosmos_minibatch_step); the host sets it on the struct it later passes as `prev` / to
                                   tq_cosmos_tail */
-  int32_t* sync;               /* [4] zero-initialised words of tq_cosmos_minibatch_step (workgroup tickets, flag), or NULL */
+  int32_t* sync;               /* [4] zero-initialised device words, or NULL: [0..2] workgroup tickets, flag and completion count of
+                                  tq_cosmos_minibatch_step; [3] completion ticket of the per-AOI sums of a full-batch step with
+                                  rows (tq_cosmos_elbo_grads / tq_cosmos_tail; without `sync` those take the flat layout / the
+                                  single-workgroup tail).  Every launch leaves the counters re-armed. */
   int32_t sync_value;          /* value the flag takes in this launch: any value different from the previous launch's on the
                                   same `sync` words (a launch counter of the host) */
 } tq_cosmos_args;
