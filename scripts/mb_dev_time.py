@@ -10,6 +10,10 @@ class _M: K, device = 2, dev
 data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
 eng = CosmosEngine(data, K=2, device=dev, seed=7)
 eng.layout.set_constrained(eng.params, initial_values(eng, data))
+if os.environ.get("TRAINED"):  # the parameter regime of a converged fit (scripts/site_trained.py)
+    for _ in range(int(os.environ["TRAINED"])):
+        eng.step()
+    eng.join()
 g = torch.Generator().manual_seed(0)
 nb, fb = int(os.environ.get("NB", 10)), int(os.environ.get("FB", 512))
 didx = [(torch.randperm(400, generator=g)[:nb].to(dev, torch.int32), torch.randperm(1000, generator=g)[:fb].to(dev, torch.int32)) for _ in range(200)]
