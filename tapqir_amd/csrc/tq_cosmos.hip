@@ -715,9 +715,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     __syncthreads();
   }
   TQ_STAMP(1)
-  for (int e = tid; e < NS * TQ_UNITS_PER_BLOCK; e += 256) {
-    const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
-    if (i < B) tq_body_site(a, e >> 4, i);
+  if constexpr (K <= 3) {
+    // one KIND of site per wave -- wave 0 the K+1 Gamma sites (background, heights), waves 1..3 the width / x / y sites --
+    // so that no wave runs the Gamma code and then the Beta code (with its regimes) for different lanes
+    const int w = tid >> 6, l = tid & 63;
+    const int nl = (w == 0 ? K + 1 : K) * TQ_UNITS_PER_BLOCK;
+    const int site = (w == 0 ? 0 : K + 1 + (w - 1) * K) + (l >> 4);
+    const int64_t i = u0 + (l & (TQ_UNITS_PER_BLOCK - 1));
+    if (l < nl && i < B) tq_body_site(a, site, i);
+  } else {
+    for (int e = tid; e < NS * TQ_UNITS_PER_BLOCK; e += 256) {
+      const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
+      if (i < B) tq_body_site(a, e >> 4, i);
+    }
   }
   __syncthreads();
   TQ_STAMP(2)
