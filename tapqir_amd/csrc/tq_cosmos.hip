@@ -565,6 +565,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
     if (blockIdx.x != 0) return;
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
+#ifdef TQ_MB_STAMPS  // (diagnostic build, scripts/fb_tail_time.py: how long the tail workgroup of a full-batch step lives)
+    if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[8] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
       if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
@@ -576,13 +579,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
       __threadfence();
       __syncthreads();
     }
+#ifdef TQ_MB_STAMPS
+    if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[13] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int ns = tq_num_gsites(a);
     if ((threadIdx.x & 63) == 0)
       for (int s = threadIdx.x >> 6; s < ns; s += 4) tq_body_sample_globals(a, s);
+#ifdef TQ_MB_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[11] = __builtin_amdgcn_s_memrealtime();
+#endif
     return;
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y - 1, i);
+#ifdef TQ_MB_STAMPS
+  if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0 && a.sync)
+    ((uint64_t*)(a.sync + 4))[10] = __builtin_amdgcn_s_memrealtime();  // (about) the last sampling workgroup
+#endif
 }
 
 
