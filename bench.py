@@ -425,6 +425,11 @@ def roofline_block(pb, ms_per_step, dev):
         out["step_kernel"] = {"kernel": "tq_pixel_unit_kernel<K,P> (the pixel kernel above + per-unit ELBO terms, gradients and "
                                         "Adam of the same 64 units, one launch; chosen over two launches by timing both on "
                                         f"this box: {[round(t, 4) for t in getattr(eng, 'step_times_ms', [])]} ms per step)",
+                              "timing": "HIP events: (launches x [sampling, this kernel]) - (launches x sampling), each an uninterrupted "
+                                        "sequence on the launch stream.  The difference also contains what this kernel costs the sampling "
+                                        "launch that follows it (86 MB of parameter writes still draining): the kernel-only duration in the "
+                                        "rocprofv3 trace (profiles/r02_kernel_trace_summary.txt) is ~8 % shorter, and the sampling launch of a "
+                                        "step is ~12 us longer there than back to back with itself",
                               "bytes_per_unit": sb, "units_per_launch": tot_units, "avg_launch_ms": t_pu * 1e3,
                               "achieved": tot_units * sb / t_pu / 1e9, "frac": tot_units * sb / t_pu / 1e9 / HBM_PEAK_GBS}
     tag = "c4" if eng.crosstalk else ("hist" if eng.O > 1 else ("c5" if (K, P) == (3, 20) else ("c2" if (K, P) == (2, 14) else None)))
