@@ -1,0 +1,29 @@
+"""Soak run: 10 000 full-batch steps, 40 000 minibatch steps with fresh subsamples, 300 steps alternating between the two kinds
+(pending tails handed from one kind to the other); everything must stay finite and no launch may stall."""
+import os, sys, time, torch
+sys.path.insert(0, ".")
+from tapqir_amd.models.cosmos import initial_values
+from tapqir_amd.models.engine import CosmosEngine
+from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+dev = torch.device("cuda", 0)
+class _M: K, device = 2, dev
+data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
+e = CosmosEngine(data, K=2, device=dev, seed=7)
+e.layout.set_constrained(e.params, initial_values(e, data))
+t0 = time.time()
+for it in range(10000):
+    e.step()
+e.join(); torch.cuda.synchronize()
+print("full batch 10000 steps", round(time.time() - t0, 2), "s; ELBO", float(e.elbo_out[0]), "finite", bool(torch.isfinite(e.params).all()), "fused", e.fuse_unit, "pixel_mode", e.pixel_mode)
+g = torch.Generator().manual_seed(0)
+t0 = time.time()
+for it in range(40000):
+    e.step(torch.randperm(400, generator=g)[:10], torch.randperm(1000, generator=g)[:512])
+    if it % 5000 == 4999:
+        e.join(); print("  minibatch", it + 1, float(e.elbo_out[0]), bool(torch.isfinite(e.params).all()), flush=True)
+# alternate kinds of steps (pending tails of either kind handed over)
+for it in range(300):
+    if it % 3 == 0: e.step()
+    else: e.step(torch.randperm(400, generator=g)[:10], torch.randperm(1000, generator=g)[:512])
+e.join(); torch.cuda.synchronize()
+print("minibatch 40000 + mixed 300 steps", round(time.time() - t0, 2), "s; ELBO", float(e.elbo_out[0]), "finite", bool(torch.isfinite(e.params).all()))
