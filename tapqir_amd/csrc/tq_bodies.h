@@ -62,6 +62,16 @@ TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
   tq_globals_sample_site(s, p, C, a.seed, a.step, a.draw_globals, (TqGlobalBase*)a.gbase, (TqGlobals*)a.globals);
 }
 
+// Streaming accesses (device: non-temporal loads / stores): data that is touched once per step and is not wanted in the
+// L2 -- the Adam moments of the per-unit phase (57 MB in, 57 MB out per c2 step).  Measured: 0.2381 -> 0.2306 ms per step.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TQ_LOAD_STREAM(p) __builtin_nontemporal_load(p)
+#define TQ_STORE_STREAM(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define TQ_LOAD_STREAM(p) (*(p))
+#define TQ_STORE_STREAM(v, p) (*(p) = (v))
+#endif
+
 // ---- local guide sites: work item (site, i), site in [0, 1+4K): b, h[k], w[k], x[k], y[k]; row t = site * B + i ---
 // Draws the latent (or takes it from `lat` when draw_locals == 0) and evaluates the site's guide
 // terms (tq_site.h: TQ_NSITE_TERMS per site).  Lanes of a wave share the site kind (site-major
@@ -192,8 +202,8 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
   if (a.fuse_adam && !LATE_MOMENTS) {
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
-      m_old[r] = a.exp_avg[(int64_t)r * U + ix.u];
-      v_old[r] = a.exp_avg_sq[(int64_t)r * U + ix.u];
+      m_old[r] = TQ_LOAD_STREAM(&a.exp_avg[(int64_t)r * U + ix.u]);
+      v_old[r] = TQ_LOAD_STREAM(&a.exp_avg_sq[(int64_t)r * U + ix.u]);
     }
   }
 
@@ -275,8 +285,8 @@ TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, floa
   const float g = -dELBO;
   const float m = a.beta1 * m_old + (1.0f - a.beta1) * g;
   const float v = a.beta2 * v_old + (1.0f - a.beta2) * g * g;
-  a.exp_avg[j] = m;
-  a.exp_avg_sq[j] = v;
+  TQ_STORE_STREAM(m, &a.exp_avg[j]);
+  TQ_STORE_STREAM(v, &a.exp_avg_sq[j]);
   // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps) with the 1-ulp hardware sqrt / rcp (the IEEE division and
   // square-root sequences cost ~70 instructions per parameter; the update is accurate to ~1e-7 of lr either way)
   const float rs2 = TQ_FRCP(TQ_FSQRT(a.bias_correction2));
