@@ -63,7 +63,9 @@ TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
 }
 
 // Streaming accesses (device: non-temporal loads / stores): data that is touched once per step and is not wanted in the
-// L2 -- the Adam moments of the per-unit phase (57 MB in, 57 MB out per c2 step).  Measured: 0.2381 -> 0.2306 ms per step.
+// L2 -- the Adam moments of the per-unit phase of a FULL-BATCH step (57 MB in, 57 MB out at c2; 0.2381 -> 0.2306 ms per
+// step on one box, 0.2394 -> 0.2384 on another).  Not in minibatch steps, whose per-unit phase reads what the replay of
+// the same launch has just written (53.5 -> 55.7 us with the hint).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TQ_LOAD_STREAM(p) __builtin_nontemporal_load(p)
 #define TQ_STORE_STREAM(v, p) __builtin_nontemporal_store(v, p)
@@ -129,6 +131,7 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
 }
 
 TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO);
+template <bool STREAM = false>
 TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, float dELBO, float m_old, float v_old);
 
 // ---- per-unit ELBO terms and gradients --------------------------------------------------------------------
@@ -139,7 +142,8 @@ TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, floa
 // runs at twice the occupancy of tq_unit_kernel and cannot afford the 4K+... registers that holding them costs).
 // pixv != nullptr: the pixel kernel's results for this unit (the rows of a.pix, in row order) are taken from there (the
 // fused pixel + per-unit kernel hands them over in registers).
-template <int K, bool LATE_MOMENTS = false>
+// STREAM: the Adam moments are read and written with non-temporal accesses (full-batch steps: touched once per step).
+template <int K, bool LATE_MOMENTS = false, bool STREAM = false>
 TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* aoi2 = nullptr, const float* pixv = nullptr) {
   constexpr int M = 1 << K;
   constexpr int NL = TQ_NLOCAL(K);
@@ -202,8 +206,8 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
   if (a.fuse_adam && !LATE_MOMENTS) {
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
-      m_old[r] = TQ_LOAD_STREAM(&a.exp_avg[(int64_t)r * U + ix.u]);
-      v_old[r] = TQ_LOAD_STREAM(&a.exp_avg_sq[(int64_t)r * U + ix.u]);
+      m_old[r] = STREAM ? TQ_LOAD_STREAM(&a.exp_avg[(int64_t)r * U + ix.u]) : a.exp_avg[(int64_t)r * U + ix.u];
+      v_old[r] = STREAM ? TQ_LOAD_STREAM(&a.exp_avg_sq[(int64_t)r * U + ix.u]) : a.exp_avg_sq[(int64_t)r * U + ix.u];
     }
   }
 
@@ -220,7 +224,7 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
     }
 #pragma unroll
     for (int r = 0; r < NL; ++r)
-      tq_adam_apply_given(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r], m_old[r], v_old[r]);
+      tq_adam_apply_given<STREAM>(a, (int64_t)r * U + ix.u, in.u[r], masked ? 0.0f : out.g[r], m_old[r], v_old[r]);
     if (a.last_step) a.last_step[ix.u] = (int32_t)(a.step + 1);  // lazy Adam clock of the unit
   } else {
 #pragma unroll
@@ -281,12 +285,18 @@ TQ_HD double tq_body_globals_grad(const tq_cosmos_args& a, int s) {
 TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO) {
   tq_adam_apply_given(a, j, p, dELBO, a.exp_avg[j], a.exp_avg_sq[j]);
 }
+template <bool STREAM>
 TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, float dELBO, float m_old, float v_old) {
   const float g = -dELBO;
   const float m = a.beta1 * m_old + (1.0f - a.beta1) * g;
   const float v = a.beta2 * v_old + (1.0f - a.beta2) * g * g;
-  TQ_STORE_STREAM(m, &a.exp_avg[j]);
-  TQ_STORE_STREAM(v, &a.exp_avg_sq[j]);
+  if (STREAM) {
+    TQ_STORE_STREAM(m, &a.exp_avg[j]);
+    TQ_STORE_STREAM(v, &a.exp_avg_sq[j]);
+  } else {
+    a.exp_avg[j] = m;
+    a.exp_avg_sq[j] = v;
+  }
   // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps) with the 1-ulp hardware sqrt / rcp (the IEEE division and
   // square-root sequences cost ~70 instructions per parameter; the update is accurate to ~1e-7 of lr either way)
   const float rs2 = TQ_FRCP(TQ_FSQRT(a.bias_correction2));

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64, 2) void tq_pixel_unit_kernel(const tq_ksmogn_ar
   for (int j = 0; j < TQ_ROWS_GCOL; ++j) aoi[j] = 0.0f;
   if (i < B) {
     float aoi2[2];
-    tq_body_unit<K>(a, i, part, aoi2, pixv);
+    tq_body_unit<K, false, true>(a, i, part, aoi2, pixv);
     const uint32_t n = (uint32_t)i / FC;
     const int c = (int)((uint32_t)i % (uint32_t)a.C);
     const int slot = n == n0 ? 0 : 1;
