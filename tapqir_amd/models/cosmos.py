@@ -181,8 +181,14 @@ class cosmos(Model):
 
     def step_async(self) -> None:
         """One SVI update, nothing read back (the -ELBO stays on the device)."""
-        ndx, fdx = self._subsample()
-        self.engine.step(ndx, fdx, allreduce=self.allreduce)
+        eng = self.engine
+        if self.n is None and self.f is None and eng.device.type == "cuda" and hasattr(eng, "draw_subsample"):
+            # the same two randperm draws as _subsample, made straight into the engine's pinned staging ring
+            d = self.data
+            ndx, fdx = eng.draw_subsample(self.nbatch_size or d.Nt, self.fbatch_size or d.F, self._subsample_gen)
+        else:
+            ndx, fdx = self._subsample()
+        eng.step(ndx, fdx, allreduce=self.allreduce)
         self._probs = None
 
     def last_loss(self) -> float:

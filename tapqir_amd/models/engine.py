@@ -262,19 +262,7 @@ class CosmosEngine:
         host = [t is not None and t.device.type == "cpu" for t in (ndx, fdx)]
         if self.device.type != "cuda" or not any(host):
             return (None if ndx is None else self._index_to_device(ndx, 0)), (None if fdx is None else self._index_to_device(fdx, 1))
-        ring = self.__dict__.get("_idx_ring")
-        if ring is None:
-            n = self.Nt + self.F
-            ring = []
-            for _ in range(16):
-                pin = torch.empty(n, dtype=torch.int32).pin_memory()
-                ring.append([pin, pin.numpy(), torch.empty(n, dtype=torch.int32, device=self.device), torch.cuda.Event(), False])
-            self._idx_ring, self._idx_count = ring, 0
-        slot = ring[self._idx_count % len(ring)]
-        self._idx_count += 1
-        pin, pin_np, dev, ev, used = slot
-        if used:
-            ev.synchronize()  # the copy that last read this staging slot (16 steps ago) has completed
+        pin, pin_np, dev, ev, _ = slot = self._idx_slot()
         pos, out = 0, []
         for t, h in zip((ndx, fdx), host):
             if t is None:
@@ -290,6 +278,48 @@ class CosmosEngine:
         ev.record()  # on the current stream
         slot[4] = True
         return tuple(dev[o[0]:o[0] + o[1]] if isinstance(o, tuple) else o for o in out)
+
+    def _idx_slot(self):
+        """Next slot of the 16-deep ring of pinned + device index buffers ([Nt | F] int32 each)."""
+        ring = self.__dict__.get("_idx_ring")
+        if ring is None:
+            n = self.Nt + self.F
+            ring = []
+            for _ in range(16):
+                pin = torch.empty(n, dtype=torch.int32).pin_memory()
+                ring.append([pin, pin.numpy(), torch.empty(n, dtype=torch.int32, device=self.device), torch.cuda.Event(), False])
+            self._idx_ring, self._idx_count = ring, 0
+        slot = ring[self._idx_count % len(ring)]
+        self._idx_count += 1
+        if slot[4]:
+            slot[3].synchronize()  # the copy that last read this staging slot (16 steps ago) has completed
+        return slot
+
+    def draw_subsample(self, nb, fb, generator):
+        """``torch.randperm(Nt)[:nb]``, ``torch.randperm(F)[:fb]`` (pyro.plate's subsample, cosmos.py:194-208) drawn straight
+        into a pinned staging slot as int32 and copied to the device in ONE asynchronous copy: returns device index
+        tensors for ``step`` (None where the whole axis is taken).  Saves the slicing and int64 -> int32 copies of
+        ``_indices_to_device`` -- at the default minibatch the host, not the device, bounds ``Model.run``."""
+        if self.device.type != "cuda":
+            raise RuntimeError("draw_subsample stages through pinned memory: GPU engines only")
+        take_n, take_f = nb < self.Nt, fb < self.F
+        if not (take_n or take_f):
+            return None, None
+        pin, _, dev, ev, _ = slot = self._idx_slot()
+        Nt, F = self.Nt, self.F
+        if take_n:
+            torch.randperm(Nt, generator=generator, dtype=torch.int32, out=pin[:Nt])
+        if take_f:
+            torch.randperm(F, generator=generator, dtype=torch.int32, out=pin[Nt:Nt + F])
+        if take_n and take_f:
+            dev.copy_(pin, non_blocking=True)
+        elif take_n:
+            dev[:nb].copy_(pin[:nb], non_blocking=True)
+        else:
+            dev[Nt:Nt + fb].copy_(pin[Nt:Nt + fb], non_blocking=True)
+        ev.record()
+        slot[4] = True
+        return (dev[:nb] if take_n else None), (dev[Nt:Nt + fb] if take_f else None)
 
     def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None,
                   _for_step=False):
