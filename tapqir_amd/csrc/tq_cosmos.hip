@@ -639,6 +639,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   TQ_STAMP(6)
   const int ticket = s_ticket;
   const int flag_value = a.sync_value;
+  // every workgroup counts itself out exactly once; the last one re-arms the ticket counter for the next launch
+  auto count_out = [&]() {
+    const int done = __hip_atomic_fetch_add(&a.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {
+      __hip_atomic_store(&a.sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.sync[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (ticket >= (int)gridDim.x) {
+    // the counter did not start from zero (an earlier launch was torn down before it could re-arm it): this launch has
+    // no valid work split.  Touch nothing, leave a NaN loss, and re-arm so that the next launch is whole again.
+    if (tid == 0) {
+      a.elbo_out[0] = __builtin_nan("");
+      count_out();
+    }
+    return;
+  }
   if (ticket == 0) {  // the extra workgroup of the grid: owns no units
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
@@ -668,14 +685,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       __hip_atomic_store(&a.sync[1], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     TQ_TAIL_STAMP(11)
-    // re-arm the ticket counter when every workgroup has taken its ticket
-    if (tid == 0) {
-      const int done = __hip_atomic_fetch_add(&a.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (done == (int)gridDim.x - 1) {
-        __hip_atomic_store(&a.sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.sync[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (tid == 0) count_out();
     return;
   }
   // ---- phase 1: catch-up + site draws of this workgroup's 16 units (work index = ticket - 1) ----
@@ -764,7 +774,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   }
   __syncthreads();
   if (!s_ok) {  // never observed: leave a visible trace (NaN loss) instead of reading half-written tables
-    if (tid == 0 && wblk == 0) a.elbo_out[0] = __builtin_nan("");
+    if (tid == 0) {
+      // The step is lost.  Its row of partial sums carries a NaN ELBO, so the tail of this step (run by the next launch or
+      // by tq_cosmos_tail) reports a NaN loss whichever workgroup was late, and Model.run rolls back to its last
+      // checkpoint (model.py:220-232); CosmosEngine.reset_adam_clock zeroes the sync words on that path.
+      a.blk_part[wblk * (TQ_ROWS_GCOL + tq_num_gsum(a)) + TQ_ROWS_GCOL + TQ_GS_ELBO] = __builtin_nanf("");
+      a.elbo_out[0] = __builtin_nan("");
+      count_out();  // still counted: the ticket counter is re-armed for the launches that follow
+    }
     return;
   }
   TQ_STAMP(3)
@@ -819,13 +836,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   }
   TQ_STAMP(5)
   // the last workgroup to get here re-arms the ticket counter for the next launch (the flag holds the step number)
-  if (tid == 0) {
-    const int done = __hip_atomic_fetch_add(&a.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (int)gridDim.x - 1) {
-      __hip_atomic_store(&a.sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&a.sync[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  if (tid == 0) count_out();
 }
 
 

@@ -231,6 +231,11 @@ class CosmosEngine:
         self.join()
         self.adam_step = int(step)
         self._stale = False
+        # the ticket / flag words of the single-launch minibatch step start from a known state again: a launch that timed
+        # out waiting for its flag (the kernel then leaves a NaN loss, which brings Model.run here through its checkpoint
+        # reload) must not leave a ticket counter that no later launch can start from
+        self._sync.zero_()
+        self._sync_value = 0
 
     # -- workspace ---------------------------------------------------------------------------------
     def _workspace(self, nb, fb):
@@ -533,8 +538,8 @@ class CosmosEngine:
                 # catch-up, site draws, likelihood, per-unit terms + Adam of this step and the pending tail of the
                 # previous one in a single launch; the tail of this step stays pending
                 prev = self._tail_args
-                self._sync_value = (self._sync_value + 1) & 0x3FFFFFFF
-                a.sync_value = self._sync_value or 1
+                self._sync_value = self._sync_value % 0x3FFFFFFF + 1  # never 0, never the same value twice in a row
+                a.sync_value = self._sync_value
                 _lib.check(self.lib.tq_cosmos_minibatch_step(C.byref(a), None if prev is None else C.byref(prev),
                                                               self._stream()), "tq_cosmos_minibatch_step")
                 a.tail_kind = 1  # TQ_TAIL_ROWS16

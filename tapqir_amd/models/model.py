@@ -158,6 +158,7 @@ class Model:
             except Exception:  # pragma: no cover
                 writer_cm = _NullWriter()
         self._in_run = True
+        completed = False  # run() left through its normal exit (end of the loop or convergence), not an exception
         try:
             with writer_cm as writer:
                 for i in progress_bar(range(num_iter)):
@@ -186,12 +187,35 @@ class Model:
                         raise
                 else:
                     logger.warning(f"Iteration #{self.iter} model has not converged.")
+            completed = True
         finally:
             self._in_run = False
-            self._join_checkpoint_writer()
-            if getattr(self, "_ckpt_file_stale", False) and self.run_path is not None:
-                self._write_state_file(wait=True)  # the file of the last checkpoint(s) was left to this point
+            if completed:
+                self._join_checkpoint_writer()
+                self._final_state_file()
+            else:
+                # unwinding from an exception (device error, KeyboardInterrupt, ...): launch nothing more and leave the
+                # last good file alone -- a write here could mask the original error or store a broken state
+                try:
+                    self._join_checkpoint_writer()
+                except Exception as err:  # pragma: no cover
+                    logger.warning(f"checkpoint writer: {err!r}")
         self.iter_loss = self.last_loss()
+
+    def _final_state_file(self):
+        """End of run(): the file of the last checkpoint(s) may have been left to this point (_write_state_file).  Same
+        rule as save_checkpoint -- "save only if no NaN values" (model.py:245-250): up to 199 steps have run since the
+        last check, so the state is checked again (agreed between the ranks of a sharded fit: `_ckpt_file_stale` is
+        the same on every rank, see _write_state_file) and a non-finite state keeps the previous file."""
+        if not getattr(self, "_ckpt_file_stale", False) or self.run_path is None:
+            return
+        bad = not bool(torch.isfinite(self.engine.params).all())
+        if self.collective is not None:
+            bad = self.collective.any(bad)
+        if bad:
+            logger.warning(f"Iteration #{self.iter}: non-finite parameters at the end of run(); keeping the last checkpoint file")
+            return
+        self._write_state_file(wait=True)
 
     def set_rng_seed(self, seed):
         self.engine.seed = int(seed)
@@ -266,7 +290,12 @@ class Model:
         }
 
     def _write_state_file(self, wait=None):
-        """Write ``<run_path>/<name>_model.tpqr`` with the current state (model.py:272-289)."""
+        """Write ``<run_path>/<name>_model.tpqr`` with the current state (model.py:272-289).
+
+        Inside run() a file may be DEFERRED (helper process busy with the previous file, or still starting).  In an
+        AOI-sharded fit that decision is made collectively -- if any rank defers, all do -- so that every rank's file holds
+        the same iteration: ranks resuming from files of different iterations would disagree on `iter % 200` and issue
+        mismatched collectives.  At most two files in a row are deferred; the third is written synchronously."""
         import os
 
         self.run_path.mkdir(parents=True, exist_ok=True)
@@ -274,20 +303,37 @@ class Model:
         eng = self.engine
         wait = (not getattr(self, "_in_run", False)) if wait is None else wait
         w = getattr(self, "_ckpt_process", None)
-        if w is not None and w.n != eng.params.numel():
+        if w is not None and (w.n != eng.params.numel() or w.failed()):
+            if w.failed():
+                logger.warning(f"checkpoint helper process ended ({w.failure}); writing checkpoints in-process")
+                os.environ["TAPQIR_AMD_CKPT_PROCESS"] = "0"
+            self._ckpt_process = None
+            w.close()
             w = None
-        if w is not None and (w.busy() or w.ready()):
-            if not wait and w.busy():
+        if not wait:
+            defer = w is not None and (w.busy() or not w.ready())
+            if self.collective is not None:
+                defer = self.collective.any(defer)
+            if defer and getattr(self, "_ckpt_deferred", 0) < 2:
+                self._ckpt_deferred = getattr(self, "_ckpt_deferred", 0) + 1
                 self._ckpt_file_stale = True  # a later checkpoint, or the end of run(), writes a newer state
                 return
-            w.submit(eng.params, eng.exp_avg, eng.exp_avg_sq, self._manifest(), target)
-            self._ckpt_file_stale = False
-            if wait:
-                w.join()
-            return
-        if w is not None and not wait:  # the helper process is still starting (~1 s): leave the file to a later checkpoint
-            self._ckpt_file_stale = True
-            return
+            if defer:
+                wait = True  # two files in a row were left out already: this one is written before the fit goes on
+        self._ckpt_deferred = 0
+        if w is not None and not w.failed() and (w.busy() or w.ready() or wait):
+            try:
+                w.submit(eng.params, eng.exp_avg, eng.exp_avg_sq, self._manifest(), target)
+                if wait:
+                    w.join()
+                self._ckpt_file_stale = False
+                return
+            except RuntimeError as err:  # the helper died under this file: fall through to the in-process write
+                logger.warning(f"{err}; writing checkpoints in-process")
+                os.environ["TAPQIR_AMD_CKPT_PROCESS"] = "0"
+                self._ckpt_process = None
+                w.close()
+                w = None
         if (w is None and not wait and eng.params.device.type == "cuda"
                 and os.environ.get("TAPQIR_AMD_CKPT_PROCESS", "1") != "0"):
             # first file of a run(): written here, while the helper process for the following ones starts
@@ -298,7 +344,6 @@ class Model:
             except Exception as err:  # no /dev/shm, no child process: every file is written in-process
                 logger.warning(f"checkpoint helper process not available ({err!r}); writing checkpoints in-process")
                 os.environ["TAPQIR_AMD_CKPT_PROCESS"] = "0"
-        self._join_checkpoint_writer()
         from tapqir_amd.utils.ckpt_writer import write_file
 
         payload = {
@@ -318,7 +363,11 @@ class Model:
                 self._ckpt_process = None
                 w.close()
             else:
-                w.join()
+                try:
+                    w.join()
+                except RuntimeError as err:  # the file in flight was lost with the helper: a later one replaces it
+                    logger.warning(str(err))
+                    self._ckpt_file_stale = True
 
     def _param_store_state(self):
         """Same payload shape as pyro.get_param_store().get_state()."""

@@ -104,6 +104,7 @@ class CheckpointWriter:
         self._thread = None
         self._error = None
         self._closed = False
+        self.failure = None  # why the child is gone (torch import failure, missing /dev/shm file, OOM kill, ...)
         self.files_written = 0
         import atexit
         import weakref
@@ -121,8 +122,17 @@ class CheckpointWriter:
                 self._set_ready(self.child.stdout.readline())
         return self._ready
 
+    def failed(self):
+        """True once the child process is known to be gone (it never restarts): the caller drops this writer and writes
+        its files in-process.  Never blocks."""
+        if self.failure is None and not self._closed and self.child.poll() is not None:
+            self.failure = f"exit code {self.child.returncode}"
+        return self.failure is not None
+
     def _set_ready(self, line):
         self._ready = line.strip() == b"ready"
+        if not self._ready:  # EOF (an empty read) or anything but the greeting: the child did not come up
+            self.failure = self.failure or ("ended before it was ready" if not line else f"unexpected greeting {line[:40]!r}")
         if self._ready:  # both processes have the buffer mapped: the name can go (nothing is left behind on a crash)
             try:
                 os.unlink(self.path)
@@ -173,10 +183,14 @@ class CheckpointWriter:
                 reply = self.child.stdout.readline().decode().strip()
                 if reply != "ok":
                     self._error = reply or "the writer process ended"
+                    if not reply:
+                        self.failure = self.failure or "ended while writing a file"
                 else:
                     self.files_written += 1
-            except Exception as err:  # pragma: no cover
+            except Exception as err:  # (BrokenPipeError when the child is gone)
                 self._error = repr(err)
+                if isinstance(err, OSError):
+                    self.failure = self.failure or repr(err)
 
         self._thread = threading.Thread(target=run, name="tapqir-checkpoint")
         self._thread.start()

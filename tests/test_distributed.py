@@ -195,3 +195,89 @@ def test_sharded_model_ranks_stay_in_step(tmp_path):
     assert outs[0]["stats_dir"] != outs[1]["stats_dir"]
     for o in outs:
         assert "cosmos_params.tpqr" in o["stats_files"] and "cosmos_summary.csv" in o["stats_files"]
+
+
+def _ckpt_worker(rank, world, port, q, tmp):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import HostCheckEngine
+    from test_model_api import _FakeWriter
+    from tapqir_amd.models import cosmos
+    from tapqir_amd.parallel import attach
+
+    def fresh():
+        m = cosmos(K=2, device="cpu")
+        m.load(tmp)
+        attach(m)
+        m._make_engine(engine_cls=HostCheckEngine)
+        m.init(lr=0.005, nbatch_size=3, fbatch_size=5)
+        return m
+
+    m = fresh()
+    m.run(2, progress_bar=lambda r: r)
+    n = m.engine.params.numel()
+    m._in_run = True
+    # the helper of rank 1 is busy at iteration 200, that of rank 0 is not: BOTH ranks leave the file out
+    w = m._ckpt_process = _FakeWriter(n, busy=(rank == 1))
+    m.iter = 200
+    m._write_state_file()
+    out = {"rank": rank, "stale_200": m._ckpt_file_stale, "submitted_200": list(w.submitted)}
+    w._busy = False
+    m.iter = 400
+    m._write_state_file()
+    out["stale_400"], out["submitted_400"] = m._ckpt_file_stale, list(w.submitted)
+    m._in_run = False
+    m._ckpt_process = None
+    # end of run(): both ranks write the same iteration; a NaN on ONE rank keeps the previous file on BOTH
+    m._ckpt_file_stale = True
+    m.iter = 450
+    if rank == 1:
+        m.engine.params[0] = float("nan")
+    m._final_state_file()
+    if rank == 1:
+        m.engine.params[0] = 0.0
+    m2 = fresh()  # resume: same iteration and same global parameters on every rank
+    out["resume_iter"] = m2.iter
+    g = m2.engine.layout.constrained(m2.engine.params, {"gain_loc", "proximity_loc", "lamda_loc"})
+    out["globals"] = [float(g["gain_loc"]), float(g["proximity_loc"]), float(g["lamda_loc"][0])]
+    m.iter = 460
+    m._ckpt_file_stale = True
+    m._final_state_file()
+    out["resume_iter_2"] = fresh().iter
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_checkpoint_files_hold_the_same_iteration_on_every_rank(tmp_path):
+    """whether a checkpoint FILE is deferred, and whether the end-of-run file is written, is decided
+    collectively, so that the ranks of a sharded fit always resume from the same iteration."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tapqir_amd.utils.dataset import save
+    from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
+
+    save(simulate(2, 6, 5, 1, 14, 0, TEST_PARAMS), tmp_path)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 211) % 2000
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda o: o["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = outs
+    assert a["stale_200"] and b["stale_200"] and a["submitted_200"] == b["submitted_200"] == []
+    assert not a["stale_400"] and not b["stale_400"] and a["submitted_400"] == b["submitted_400"] == [400]
+    assert a["resume_iter"] == b["resume_iter"] == 0  # run(2) wrote iteration 0; the NaN of rank 1 kept it on both ranks
+    assert a["globals"] == b["globals"]
+    assert a["resume_iter_2"] == b["resume_iter_2"] == 460

@@ -344,3 +344,120 @@ def test_run_leaves_the_final_state_on_disk(tmp_path):
         w = getattr(model, "_ckpt_process", None)
         model._join_checkpoint_writer(close=True)
         assert w is None or not os.path.exists(w.path)
+
+
+class _FakeWriter:
+    """Stand-in for CheckpointWriter in the host-side tests of Model._write_state_file (no GPU, no child process)."""
+
+    def __init__(self, n, busy=False, ready=True, dead=False):
+        self.n, self._busy, self._rdy, self.failure = n, busy, ready, ("exit code 1" if dead else None)
+        self.submitted, self.closed = [], False
+
+    def busy(self):
+        return self._busy
+
+    def ready(self):
+        return self._rdy
+
+    def failed(self):
+        return self.failure is not None
+
+    def submit(self, p, m, v, manifest, target):
+        self.submitted.append(manifest["iter"])
+
+    def join(self):
+        pass
+
+    def close(self):
+        self.closed = True
+
+
+def _host_model(tmp_path, iters=1):
+    d = simulate(2, 4, 6, 1, 14, 0, TEST_PARAMS)
+    save(d, tmp_path)
+    m = cosmos(K=2, device="cpu")
+    m.load(tmp_path)
+    m._make_engine(engine_cls=HostCheckEngine)
+    m.init(lr=0.005, nbatch_size=2, fbatch_size=5)
+    m.run(iters, progress_bar=lambda r: r)
+    return m
+
+
+def test_checkpoint_files_deferred_at_most_twice_and_dead_helper_is_dropped(tmp_path):
+    """a helper process that died must not turn every later checkpoint into a deferred one; a busy helper
+    defers at most two files in a row."""
+    m = _host_model(tmp_path)
+    target = tmp_path / ".tapqir" / "cosmos_model.tpqr"
+    n = m.engine.params.numel()
+    m._in_run = True
+    # busy helper: two deferrals, then the third file is submitted and waited for
+    w = m._ckpt_process = _FakeWriter(n, busy=True)
+    for it, want_stale, want_sub in ((200, True, 0), (400, True, 0), (600, False, 1)):
+        m.iter = it
+        m._write_state_file()
+        assert m._ckpt_file_stale is want_stale and len(w.submitted) == want_sub
+    assert w.submitted == [600]
+    # a helper that is gone: dropped, the file is written in-process at once
+    m._ckpt_process = dead = _FakeWriter(n, dead=True)
+    m.iter = 800
+    target.unlink()
+    m._write_state_file()
+    assert dead.closed and m._ckpt_process is None and not m._ckpt_file_stale
+    assert torch.load(target, weights_only=False)["iter"] == 800
+    m._in_run = False
+
+
+def test_dead_helper_process_is_detected(tmp_path):
+    """The real CheckpointWriter with a child that exits at once (what an import failure or an OOM kill looks like)."""
+    import subprocess
+    import sys
+    import time
+
+    from tapqir_amd.utils.ckpt_writer import CheckpointWriter
+
+    w = CheckpointWriter(16, "cpu")
+    try:
+        assert not w.failed()
+        w.child.kill()
+        w.child.wait()
+        t0 = time.time()
+        while not w.failed() and time.time() - t0 < 5:
+            time.sleep(0.01)
+        assert w.failed() and w.failure
+        assert not w.ready()  # EOF on the pipe is not "ready"
+    finally:
+        w.close()
+
+
+def test_run_keeps_the_last_file_when_the_final_state_is_not_finite(tmp_path):
+    """model.py:245-250 "save only if no NaN values" also holds for the file run() writes when it ends."""
+    m = _host_model(tmp_path, iters=3)
+    target = tmp_path / ".tapqir" / "cosmos_model.tpqr"
+    before = torch.load(target, weights_only=False)
+    m._ckpt_file_stale = True
+    m.engine.params[0] = float("nan")
+    m._final_state_file()
+    after = torch.load(target, weights_only=False)
+    assert after["iter"] == before["iter"]
+    assert all(bool(torch.isfinite(t).all()) for t in after["params"]["params"].values())
+    # and a finite state IS written
+    m.engine.params[0] = 0.0
+    m.iter = 77
+    m._final_state_file()
+    assert torch.load(target, weights_only=False)["iter"] == 77 and not m._ckpt_file_stale
+
+
+def test_run_unwinding_from_an_exception_writes_nothing(tmp_path):
+    m = _host_model(tmp_path, iters=1)
+    target = tmp_path / ".tapqir" / "cosmos_model.tpqr"
+    before = torch.load(target, weights_only=False)["iter"]
+    m._ckpt_file_stale = True
+
+    def boom():
+        raise KeyboardInterrupt
+
+    m.step_async = boom
+    m.iter = 1  # not a checkpoint iteration: run() goes through step_async
+    with pytest.raises(KeyboardInterrupt):
+        m.run(5, progress_bar=lambda r: r)
+    assert torch.load(target, weights_only=False)["iter"] == before
