@@ -252,16 +252,19 @@ typedef struct {
                                   _step_overlapped / _elbo_grads wrote) or TQ_TAIL_ROWS16 (the step ran as
                                   tq_cosmos_minibatch_step); the host sets it on the struct it later passes as `prev` / to
                                   tq_cosmos_tail */
-  int32_t* sync;               /* [4] zero-initialised device words, or NULL: [0..2] workgroup tickets, flag and completion count of
+  int32_t* sync;               /* [TQ_SYNC_WORDS] zero-initialised device words, or NULL: [0..2] workgroup tickets, flag and completion count of
                                   tq_cosmos_minibatch_step; [3] completion ticket of the per-AOI sums of a full-batch step with
                                   rows (tq_cosmos_elbo_grads / tq_cosmos_tail; without `sync` those take the flat layout / the
-                                  single-workgroup tail).  Every launch leaves the counters re-armed. */
+                                  single-workgroup tail); [40] count of the row groups added inside the sampling launch of
+                                  tq_cosmos_step_overlapped (without `sync` its tail workgroup adds all rows itself).  Every
+                                  launch leaves the counters re-armed. */
   int32_t sync_value;          /* value the flag takes in this launch: any value different from the previous launch's on the
                                   same `sync` words (a launch counter of the host) */
 } tq_cosmos_args;
 
 #define TQ_TAIL_AUTO 0
 #define TQ_TAIL_ROWS16 1
+#define TQ_SYNC_WORDS 64
 #define TQ_PIXEL_FUSED_UNIT 2      /* tq_cosmos_args.pixel_mode: pixel + per-unit kernel of a full-batch step in one launch */
 
 int64_t tq_globals_size(void);

@@ -14,6 +14,6 @@ for _ in range(50): e.step()
 torch.cuda.synchronize()
 st = e._sync[4:32].cpu().view(torch.int64)
 t = lambda i: (int(st[i]) - int(st[8])) / 100.0
-print("tail workgroup of the previous step inside the sampling launch (us after its start): sums + per-AOI + global sites %.1f, "
-      "Adam of the per-AOI / global parameters %.1f, global draws of this step %.1f; (about) the last sampling workgroup %.1f"
-      % (t(12) if int(st[12]) > int(st[8]) else float("nan"), t(13), t(11), t(10)))
+print("tail workgroup of the previous step inside the sampling launch (us after its start): row / group sums loaded %.1f, gsum written %.1f, "
+      "global sites done %.1f, Adam of the per-AOI / global parameters %.1f, global draws of this step %.1f; (about) the last sampling workgroup %.1f"
+      % (t(9) if int(st[9]) > int(st[8]) else float("nan"), t(12) if int(st[12]) > int(st[8]) else float("nan"), t(7), t(13), t(11), t(10)))

@@ -1,12 +1,16 @@
 #!/bin/bash
-# A/B an environment toggle on one box: usage gpu_ab_env.sh VAR val1 val2 ...
+# A/B of environment switches on the same box and the same library: each argument is "NAME=VALUE[,NAME=VALUE...]" (or "-" for
+# the defaults); full bench line without the CPU leg, 3 rounds interleaved.  TRAINED=4000 adds the trained-regime leg.
 set -u
-var=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2 3; do
-  for v in "$@"; do
-    env $var=$v timeout -k 10 200 python bench.py --steps 30 --warmup 3 --no-cpu 2>/dev/null | python -c "
+  for cfg in "$@"; do
+    envs=""
+    [ "$cfg" != "-" ] && envs=$(echo $cfg | tr ',' ' ')
+    env $envs timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu --trained-steps ${TRAINED:-0} 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('$var=$v', 'step_ms=%.4f'%d['ms_per_step'], 'pix_bwd_ms=%.4f'%d['roofline']['avg_launch_ms'], 'pix_fwd_ms=%.4f'%d['roofline']['forward_only']['avg_launch_ms'], 'mb_ms=%.4f'%d['minibatch_10x512']['ms_per_step'])"
+r=d['roofline']
+print('$cfg', 'step_ms=%.4f'%d['ms_per_step'], 'mb_ms=%.4f'%d['minibatch_10x512']['ms_per_step'], 'trained=%.4f'%d.get('trained_regime',{}).get('ms_per_step',float('nan')), 'steps both ways', getattr(sys.modules[__name__],'x',None) or [v for k,v in r.items() if k=='step_kernel'] and r['step_kernel']['kernel'][-45:])"
   done
 done

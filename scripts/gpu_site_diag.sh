@@ -4,7 +4,7 @@
 # (scripts/site_breakdown.py) and in the trained regime (scripts/site_trained.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-for v in base NO_BETAGRAD NO_BETALP NO_GAMMAGRAD; do
+for v in ${VARIANTS:-base NO_BETAGRAD NO_BETALP NO_GAMMAGRAD}; do
   lib=tapqir_amd/libtapqir_hip_diag_$v.so
   [ -f $lib ] || continue
   echo "== $v"

@@ -78,25 +78,38 @@ TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
 // Draws the latent (or takes it from `lat` when draw_locals == 0) and evaluates the site's guide
 // terms (tq_site.h: TQ_NSITE_TERMS per site).  Lanes of a wave share the site kind (site-major
 // order), so the Gamma and Beta code paths do not diverge inside a wave.
-TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
+// The body in three parts (the sampling kernels put a workgroup-wide regime compaction between the draw and the terms of
+// the AffineBeta sites, tq_cosmos.hip: tq_site_beta_compact):
+//   tq_site_draw   parameters -> draw (or the given value), everything the terms need
+//   tq_site_terms  log q, its derivatives, implicit gradients (dd: the pair of tq_dirichlet_grad values if the caller
+//                  has them already)
+//   tq_site_store
+struct TqSiteDraw {
+  float val;
+  float p0, p1;  // Gamma: loc, beta;  AffineBeta: mean, size
+  float lo, hi;  // AffineBeta
+  int64_t t;     // row of the site in lat / site
+};
+TQ_HD TqSiteDraw tq_site_draw(const tq_cosmos_args& a, int site, int64_t i) {
   const int K = a.K;
   const int64_t B = tq_batch_units(a), U = tq_num_units(a);
-  const int64_t NS = (int64_t)(1 + 4 * K) * B;
-  const int64_t t = (int64_t)site * B + i;
+  TqSiteDraw d;
+  d.t = (int64_t)site * B + i;
   const TqUnitIdx ix = tq_decode_unit(a, i);
   const float* P = a.params;
   TqPhilox s;
   tq_philox_init(&s, a.seed, a.step, (uint32_t)site, ix.elem);
   const float tiny = 1.17549435e-38f;
-  float val = a.lat[t];
-  float terms[TQ_NSITE_TERMS];
+  d.val = a.lat[d.t];
+  d.lo = d.hi = 0.0f;
   if (site <= K) {  // Gamma(loc*beta, beta): background (site 0) or height
     const int rl = site == 0 ? TQ_ROW_BLOC(K) : TQ_ROW(TQ_P_HLOC, site - 1, K);
     const int rb = site == 0 ? TQ_ROW_BBETA(K) : TQ_ROW(TQ_P_HBETA, site - 1, K);
     const float ul = P[rl * U + ix.u], ub = P[rb * U + ix.u];
     const float loc = TQ_FEXP(ul), beta = TQ_FEXP(ub);
-    if (a.draw_locals) val = fmaxf(tq_sample_std_gamma(&s, loc * beta) * TQ_FRCP(beta), tiny);
-    tq_gamma_site_terms(val, loc, beta, terms);
+    if (a.draw_locals) d.val = fmaxf(tq_sample_std_gamma(&s, loc * beta) * TQ_FRCP(beta), tiny);
+    d.p0 = loc;
+    d.p1 = beta;
   } else {  // AffineBeta
     const int j = site - 1 - K;
     const int kind = j / K, k = j % K;  // 0: width, 1: x, 2: y
@@ -120,14 +133,28 @@ TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
       const float g1 = tq_sample_std_gamma(&s, c1), g0 = tq_sample_std_gamma(&s, c0);
       float tt = g1 * TQ_FRCP(g1 + g0);
       tt = fminf(fmaxf(tt, tiny), 1.0f - 5.96046448e-08f);  // torch._sample_dirichlet clamp
-      val = fminf(fmaxf(lo + sc * tt, lo + a.eps * sc), hi - a.eps * sc);  // pyro AffineBeta.rsample clamp
+      d.val = fminf(fmaxf(lo + sc * tt, lo + a.eps * sc), hi - a.eps * sc);  // pyro AffineBeta.rsample clamp
     }
-    tq_affine_beta_site_terms(val, mean, size, lo, hi, a.eps, terms);
+    d.p0 = mean;
+    d.p1 = size;
+    d.lo = lo;
+    d.hi = hi;
   }
-  a.lat[t] = val;
+  return d;
+}
+TQ_HD void tq_site_store(const tq_cosmos_args& a, int site, const TqSiteDraw& d, const float* terms) {
+  const int64_t NS = (int64_t)(1 + 4 * a.K) * tq_batch_units(a);
+  a.lat[d.t] = d.val;
 #pragma unroll
   for (int j = 0; j < TQ_NSITE_TERMS; ++j)
-    if (j < 5 || site > K) a.site[(int64_t)j * NS + t] = terms[j];  // Gamma sites have five terms: slot 5 is never read
+    if (j < 5 || site > a.K) a.site[(int64_t)j * NS + d.t] = terms[j];  // Gamma sites have five terms: slot 5 is never read
+}
+TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
+  const TqSiteDraw d = tq_site_draw(a, site, i);
+  float terms[TQ_NSITE_TERMS];
+  if (site <= a.K) tq_gamma_site_terms(d.val, d.p0, d.p1, terms);
+  else tq_affine_beta_site_terms(d.val, d.p0, d.p1, d.lo, d.hi, a.eps, terms);
+  tq_site_store(a, site, d, terms);
 }
 
 TQ_HD void tq_adam_apply(const tq_cosmos_args& a, int64_t j, float p, float dELBO);

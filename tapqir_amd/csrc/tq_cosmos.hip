@@ -30,10 +30,208 @@ __global__ __launch_bounds__(64) void tq_sample_globals_kernel(const tq_cosmos_a
   if (threadIdx.x == 0) tq_body_sample_globals(a, blockIdx.x);
 }
 
+// ---- regime compaction of the AffineBeta implicit gradients -------------------------------------------------------
+// torch's _dirichlet_grad is piecewise (two series regimes, a saddle-point expansion, a rational fit) and a wave executes
+// every regime one of its lanes needs.  At the reference's initial parameters all draws sit in the saddle-point regime;
+// in a converged fit the guide concentrations of absent spots have shrunk (size 5..18) and the lanes of EVERY wave are
+// spread over all of them (scripts/regime_mix.py: per lane 0.50 pair / 0.40 x-small series / 0.10 (1-x)-small series /
+// 0.40 rational, per wave 1.0 each), which made the sampling launch the largest of the step (157 us against 75).
+// Here the workgroup (256 draws of one site kind) first classifies its draws, writes one task per needed evaluation into
+// a queue in LDS ordered by regime, and evaluates the queue with consecutive lanes on consecutive tasks: a wave then runs
+// one regime (two at a boundary), and each regime runs on as many waves as its tasks fill.  Same routines on the same
+// arguments as tq_affine_beta_site_terms: bit-identical results.  Workgroups whose draws are all in the common
+// (saddle-point pair) class skip the queue.
+#define TQ_BC_NT 256
+// Task queues in LDS.  A draw needs at most two evaluations, so the five classes fit three regions filled from both ends
+// (no class needs another one's count before it can write): R1 = {x-small series up, rational down}, R2 = {pair up,
+// (1-x)-small series down}, R3 = {saddle point of one direction}.  One 16-byte record per task.
+struct TqBetaCompactLds {
+  float4 r1[2 * TQ_BC_NT], r2[2 * TQ_BC_NT], r3[TQ_BC_NT];  // {draw, its alpha, size, bits((lane << 2) | direction code)}
+  float c0[TQ_BC_NT];                                       // class 3: the other direction's alpha (rounding fallback)
+  float res[2 * TQ_BC_NT];
+  int cnt[8];                                               // tasks per class
+};
+
+__device__ __forceinline__ int tq_mbcnt(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// slot of task number k of class c in its region
+__device__ __forceinline__ float4* tq_bc_slot(TqBetaCompactLds& L, int c, int k) {
+  switch (c) {
+    case 0: return &L.r2[k];
+    case 1: return &L.r1[k];
+    case 2: return &L.r2[2 * TQ_BC_NT - 1 - k];
+    case 3: return &L.r3[k];
+    default: return &L.r1[2 * TQ_BC_NT - 1 - k];
+  }
+}
+
+__device__ __forceinline__ void tq_site_beta_compact(const tq_cosmos_args& a, const int site, const int64_t i, const bool live,
+                                                     TqBetaCompactLds& L) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 8) L.cnt[tid] = 0;
+  __syncthreads();  // (at the top of the kernel: every wave arrives at once)
+  TqSiteDraw d;
+  float t = 0.0f, c1 = 0.0f, c0 = 0.0f, size = 0.0f;
+  int r0 = -1, r1 = -1;
+  bool pair = false, clamped = true;
+  if (live) {
+    d = tq_site_draw(a, site, i);
+    const float sc = d.hi - d.lo, rsc = TQ_FRCP(sc);  // (the expressions of tq_affine_beta_site_terms)
+    t = (d.val - d.lo) * rsc;
+    size = d.p1;
+    c1 = size * (d.p0 - d.lo) * rsc;
+    c0 = size * (d.hi - d.p0) * rsc;
+    clamped = (d.val <= d.lo + a.eps * sc) || (d.val >= d.hi - a.eps * sc);
+#ifdef TQ_DIAG_NO_BETAGRAD  // (diagnostic builds, scripts/gpu_site_diag.sh: no gradient is evaluated)
+    clamped = true;
+#endif
+    if (!clamped) {
+      pair = tq_beta_grad_pair_applies((double)t, (double)c1, (double)size - (double)c1);
+      if (!pair) {
+        const double total = size;
+        r0 = tq_dirichlet_grad_regime((double)t, (double)c1, total - (double)c1, total);
+        r1 = tq_dirichlet_grad_regime((double)(1.0f - t), (double)c0, total - (double)c0, total);
+      }
+    }
+  }
+  // A wave whose draws are all in the common class (saddle-point pair: every wave at the reference's initial parameters)
+  // is already uniform: it evaluates in place and only joins the barriers (and the evaluation of other waves' tasks).
+  float dd[2] = {0.0f, 0.0f};
+  const bool wave_mixed = __ballot(r0 >= 0) != 0;
+  if (!wave_mixed) {
+    if (pair) {
+      double ga = t, gb = c1;
+#ifndef TQ_DIAG_NO_RP
+      tq_beta_grad_pair_mid((double)t, (double)c1, (double)size - (double)c1, &ga, &gb);
+#endif
+      dd[0] = (float)ga;
+      dd[1] = (float)gb;
+    }
+  } else {
+    // tasks per class: 0 pair (both directions of a draw), 1 x-small series, 2 (1-x)-small series, 3 saddle point of one
+    // direction (the pair routine with the boundary test off), 4 rational
+    int k[5], pos[5];
+    k[0] = pair ? 1 : 0;
+    k[1] = (r0 == 0) + (r1 == 0);
+    k[2] = (r0 == 1) + (r1 == 1);
+    k[3] = (r0 == 2 || r1 == 2) ? 1 : 0;
+    k[4] = (r0 == 3) + (r1 == 3);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const uint64_t m1 = __ballot(k[c] >= 1), m2 = __ballot(k[c] == 2);
+      const int n = __popcll(m1) + __popcll(m2);
+      int base = 0;
+      if (lane == 0 && n) base = atomicAdd(&L.cnt[c], n);  // (LDS; the order of the waves does not matter: a task's result
+      pos[c] = __shfl(base, 0, 64) + tq_mbcnt(m1) + tq_mbcnt(m2);  //  does not depend on its place in the queue)
+    }
+    auto put = [&](int c, int kk, float x, float al, int code) {
+      *tq_bc_slot(L, c, kk) = make_float4(x, al, size, __int_as_float((tid << 2) | code));
+    };
+    if (k[0]) put(0, pos[0], t, c1, 0);
+    if (k[3]) {
+      put(3, pos[3], t, c1, (r0 == 2 ? 1 : 0) | (r1 == 2 ? 2 : 0));
+      L.c0[tid] = c0;
+    }
+    {
+      const float xf[2] = {t, 1.0f - t}, af[2] = {c1, c0};
+      const int rr[2] = {r0, r1};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = rr[j];
+        if (r == 0) put(1, pos[1]++, xf[j], af[j], j);
+        if (r == 1) put(2, pos[2]++, xf[j], af[j], j);
+        if (r == 3) put(4, pos[4]++, xf[j], af[j], j);
+      }
+    }
+    L.res[2 * tid] = 0.0f;
+    L.res[2 * tid + 1] = 0.0f;
+  }
+  __syncthreads();
+  int n_c[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) n_c[c] = L.cnt[c];
+  if (n_c[0] + n_c[1] + n_c[2] + n_c[3] + n_c[4] != 0) {
+    // One loop per class, so that each regime's code and registers stand alone; the classes start on successive waves
+    // (class c on the wave after the last one of class c-1), which spreads the ~1.4 evaluations per draw of a converged fit
+    // evenly over the four waves.
+    int wave0 = 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int n = n_c[c];
+      const int slot = (((wave - wave0) & (TQ_BC_NT / 64 - 1)) << 6) | lane;
+      for (int qc = slot; qc < n; qc += TQ_BC_NT) {
+        const float4 rec = *tq_bc_slot(L, c, qc);
+        const float x = rec.x, al = rec.y, sz = rec.z;
+        const int dst = __float_as_int(rec.w) >> 2, code = __float_as_int(rec.w) & 3;
+        const double total = sz;
+        if (c == 0) {
+          double ga = x, gb = al;
+#ifndef TQ_DIAG_NO_RP  // (diagnostic builds, scripts/gpu_site_diag.sh: one regime's routine compiled out)
+          tq_beta_grad_pair_mid((double)x, (double)al, total - (double)al, &ga, &gb);
+#endif
+          L.res[2 * dst] = (float)ga;
+          L.res[2 * dst + 1] = (float)gb;
+        } else if (c == 1) {
+#ifdef TQ_DIAG_NO_R0
+          L.res[2 * dst + code] = x;
+#else
+          L.res[2 * dst + code] = (float)tq_beta_grad_alpha_small((double)x, (double)al, total - (double)al);
+#endif
+        } else if (c == 2) {
+#ifdef TQ_DIAG_NO_R1
+          L.res[2 * dst + code] = x;
+#else
+          L.res[2 * dst + code] = -tq_beta_grad_beta_small_f(1.0f - x, sz - al, al);
+#endif
+        } else if (c == 3) {
+          double ga = 0.0, gb = 0.0;
+          if (!tq_beta_grad_pair_mid<true>((double)x, (double)al, total - (double)al, &ga, &gb)) {
+            // (the two directions disagree about alpha, beta > 6 within rounding: the plain evaluation, as tq_beta_grad_pair_rest)
+            const float c0q = L.c0[dst];
+            ga = tq_beta_grad_alpha_mid((double)x, (double)al, total - (double)al);
+            gb = tq_beta_grad_alpha_mid((double)(1.0f - x), (double)c0q, total - (double)c0q);
+          }
+          if (code & 1) L.res[2 * dst] = (float)ga;
+          if (code & 2) L.res[2 * dst + 1] = (float)gb;
+        } else {
+#ifdef TQ_DIAG_NO_R3
+          L.res[2 * dst + code] = x;
+#else
+          L.res[2 * dst + code] = tq_beta_grad_rational(x, al, sz);
+#endif
+        }
+      }
+      wave0 += (n + 63) >> 6;
+    }
+    __syncthreads();
+    if (wave_mixed) {
+      dd[0] = L.res[2 * tid];
+      dd[1] = L.res[2 * tid + 1];
+    }
+  }
+  if (live) {
+    float terms[TQ_NSITE_TERMS];
+    tq_affine_beta_site_terms(d.val, d.p0, d.p1, d.lo, d.hi, a.eps, terms, dd);
+    tq_site_store(a, site, d, terms);
+  }
+}
+
+// one site of one unit per lane; workgroups are uniform in the site (grid.y), AffineBeta sites go through the compaction
+__device__ __forceinline__ void tq_sample_site_wg(const tq_cosmos_args& a, const int site, const int64_t i, const int64_t B) {
+  if (site > a.K) {
+    __shared__ TqBetaCompactLds s_bc;
+    tq_site_beta_compact(a, site, i, i < B, s_bc);
+  } else if (i < B) {
+    tq_body_site(a, site, i);
+  }
+}
+
 // grid.y = site: the site kind (Gamma / AffineBeta, which parameter rows) is uniform per workgroup
 __global__ __launch_bounds__(256) void tq_sample_locals_kernel(const tq_cosmos_args a, const int64_t B, const int site_begin) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y, i);
+  tq_sample_site_wg(a, site_begin + (int)blockIdx.y, i, B);
 }
 
 // ---- per-unit terms ------------------------------------------------------------------------------------
@@ -301,6 +499,74 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
   }
 }
 
+// ---- group rows: the tail's sums, spread over the otherwise idle workgroups of the sampling launch --------------------
+// At c2 the fused launch leaves 6250 rows (one per wave).  The single-workgroup tail that adds them is a guest of the next
+// step's sampling launch, and under that launch's memory traffic each of its ~17 dependent round trips (per-AOI frame
+// sums: 16 rows per AOI, two AOIs per thread; cross-unit sums: 25 rows per thread) takes ~2.5 us: the sums alone kept it
+// busy for 50 of its 84 us, which made it the last workgroup of the launch.  The grid row of that launch that holds the
+// tail workgroup has B / 256 workgroups of which only the first did anything: now workgroup 1 + g of that row adds the rows
+// of GROUP g (4096 units: 64 rows of 64 units or 16 of 256) -- one lane per row, one round trip -- and leaves a group row:
+// the cross-unit sums in double and the per-AOI frame sums of the (at most 17) AOIs the group touches, published with
+// write-through (`sc1`) stores, a drained store queue and an agent-scope counter (MI355X_MICROARCH.md, inter-workgroup
+// visibility).  The tail workgroup polls the counter, then reads U / 4096 group rows with `sc1` loads: one round trip for
+// the cross-unit sums, one for the per-AOI sums (stamps build: sums complete 9 us after its start instead of 50).  The
+// reducers never wait, so the polling workgroup cannot deadlock.
+#define TQ_GRP_UNITS 4096
+#define TQ_GRP_AOIS (TQ_GRP_UNITS / TQ_UNIT_BLOCK + 1)   /* AOIs a group can touch (F * C >= TQ_UNIT_BLOCK) */
+#define TQ_GGROW (2 * 16 + TQ_GRP_AOIS * 2 * TQ_MAXQ)    /* floats of a group row: 16 doubles, then 2 * TQ_MAXQ floats per AOI */
+#define TQ_SYNC_GROUPS 40                                /* word of tq_cosmos_args.sync that counts the finished groups */
+__host__ __device__ __forceinline__ int64_t tq_grp_count(int64_t B) { return (B + TQ_GRP_UNITS - 1) / TQ_GRP_UNITS; }
+// group rows follow the rows in blk_part (16-byte aligned)
+__host__ __device__ __forceinline__ int64_t tq_grp_base(int64_t nrows, int ncol) { return ((nrows * ncol + 3) / 4) * 4; }
+
+// one wave: rows of group g of step `a` -> group row g (published)
+__device__ __forceinline__ void tq_group_reduce_rows(const tq_cosmos_args& a, const int g) {
+  const int lane = threadIdx.x & 63;
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  const int64_t B = tq_batch_units(a);
+  const uint32_t UPR = (uint32_t)tq_rows_upr(a), RPG = TQ_GRP_UNITS / UPR;
+  const int64_t nrows = (B + UPR - 1) / UPR;
+  const int64_t r0 = (int64_t)g * RPG;
+  const int nw = (int)((nrows - r0) < (int64_t)RPG ? (nrows - r0) : (int64_t)RPG);
+  const bool have = lane < nw;
+  const float* my = a.blk_part + (r0 + (have ? lane : 0)) * ncol;
+  float s0[2 * TQ_MAXQ], s1[2 * TQ_MAXQ], col[TQ_MAX_NGSUM];
+#pragma unroll
+  for (int j = 0; j < 2 * TQ_MAXQ; ++j) {
+    const bool used = j < 2 * a.C;
+    s0[j] = (have && used) ? my[j] : 0.0f;
+    s1[j] = (have && used) ? my[TQ_ROWS_AOICOL + j] : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) col[j] = (have && j < nq) ? my[TQ_ROWS_GCOL + j] : 0.0f;
+  float* grow = a.blk_part + tq_grp_base(nrows, ncol) + (int64_t)g * TQ_GGROW;
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const double sum = tq_wave_sum_d((double)col[j]);
+      if (lane == 0) __hip_atomic_store(&((double*)grow)[j], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  const uint32_t FC = (uint32_t)(a.fb * a.C);
+  const uint32_t u_first = (uint32_t)g * TQ_GRP_UNITS;
+  const uint32_t u_last = (uint32_t)(((int64_t)u_first + TQ_GRP_UNITS - 1 < B - 1) ? u_first + TQ_GRP_UNITS - 1 : B - 1);
+  const uint32_t n_lo = u_first / FC, n_hi = u_last / FC;
+  const uint32_t n0 = (u_first + UPR * (uint32_t)lane) / FC;  // AOI of this row's first unit (slot 0; slot 1 is the next AOI)
+  for (uint32_t n = n_lo; n <= n_hi; ++n) {
+    float* out = grow + 32 + (n - n_lo) * (2 * TQ_MAXQ);
+#pragma unroll
+    for (int j = 0; j < 2 * TQ_MAXQ; ++j) {
+      if (j < 2 * a.C) {
+        const float v = (n0 == n) ? s0[j] : ((n0 + 1 == n) ? s1[j] : 0.0f);
+        const float sum = tq_wave_sum(v);
+        if (lane == 0) __hip_atomic_store(&out[j], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group row has left
+  if (lane == 0) __hip_atomic_fetch_add(a.sync + TQ_SYNC_GROUPS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Fused pixel + per-unit kernel of full-batch steps (pixel_mode = TQ_PIXEL_FUSED_UNIT): a wave renders its tile of 64
 // units (tq_il2_lane, the routine of tq_ksmogn_il2_kernel) and goes straight on to the per-unit terms + Adam of the same
 // 64 units, lane for lane.  The pixel phase is bound by VALU issue (PMC: ~75 % busy) and the per-unit phase by HBM
@@ -482,9 +748,85 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   __threadfence_block();
   __syncthreads();
 #ifdef TQ_MB_STAMPS
-  if (UPR_T == 16 && threadIdx.x == 0) ((uint64_t*)(a.sync + 4))[12] = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[12] = __builtin_amdgcn_s_memrealtime();
 #endif
   tq_globals_from_gsum_body(a, s_e);
+}
+
+// Tail of a step from the group rows that the reducer workgroups of the same launch publish (ONE workgroup of 256 threads):
+// waits for them, then per-AOI sites from the one or two groups that overlap the AOI, cross-unit sums, global sites and
+// the total ELBO.  Returns false after ~2 s without the reducers (never observed; the caller leaves a NaN loss).
+__device__ __forceinline__ bool tq_groups_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+  const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
+  const int64_t B = tq_batch_units(a);
+  const uint32_t UPR = (uint32_t)tq_rows_upr(a);
+  const int64_t nrows = (B + UPR - 1) / UPR;
+  const int ngroups = (int)tq_grp_count(B);
+  const float* grows = a.blk_part + tq_grp_base(nrows, ncol);
+  const uint32_t FC = (uint32_t)(a.fb * a.C);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    int ok = 1;
+    while (__hip_atomic_load(a.sync + TQ_SYNC_GROUPS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngroups) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        ok = 0;
+        break;
+      }
+    }
+    __hip_atomic_store(a.sync + TQ_SYNC_GROUPS, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) return false;
+  auto ld = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ldd = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  double acc[TQ_MAX_NGSUM];
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) acc[j] = 0.0;
+  const int nac = a.nb * a.C;
+  for (int ac = threadIdx.x; ac < nac; ac += 256) {
+    const uint32_t ai = (uint32_t)ac / (uint32_t)a.C;
+    const int c = ac - (int)ai * a.C;
+    const uint32_t g_lo = (ai * FC) / TQ_GRP_UNITS, g_hi = ((ai + 1) * FC - 1) / TQ_GRP_UNITS;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t g = g_lo; g <= g_hi; ++g) {
+      const uint32_t m = ai - (g * TQ_GRP_UNITS) / FC;
+      const float* p = grows + (int64_t)g * TQ_GGROW + 32 + m * (2 * TQ_MAXQ) + 2 * c;
+      s1 += ld(p);
+      s2 += ld(p + 1);
+    }
+    float e;
+    tq_body_aoi_finish(a, (int)ai, c, s1, s2, &e);
+    acc[TQ_GS_ELBO] += (double)e;
+  }
+  for (int g = threadIdx.x; g < ngroups; g += 256) {
+    const double* p = (const double*)(grows + (int64_t)g * TQ_GGROW);
+#pragma unroll
+    for (int j = 0; j < TQ_MAX_NGSUM; ++j)
+      if (j < nq) acc[j] += ldd(p + j);
+  }
+#ifdef TQ_MB_STAMPS
+  if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[9] = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+  for (int j = 0; j < TQ_MAX_NGSUM; ++j) {
+    if (j < nq) {
+      const double s = tq_wave_sum_d(acc[j]);
+      if (lane == 0) s_w[wave][j] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+  __threadfence_block();
+  __syncthreads();
+#ifdef TQ_MB_STAMPS
+  if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[12] = __builtin_amdgcn_s_memrealtime();
+#endif
+  tq_globals_from_gsum_body(a, s_e);
+  return true;
 }
 
 // AOI-sharded full-batch steps: rows -> per-AOI sites and gsum (what the all-reduce needs), nothing of the global
@@ -557,12 +899,22 @@ __global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_co
 // of the per-AOI / global parameters -- and then draws the global sites of step t from the updated parameters.  The
 // sampling of the local sites reads local parameters only (already updated by the Adam fused into the unit kernel of
 // step t-1), so the ~35 us latency chain of the tail hides behind the ~14 000 sampling workgroups of the same launch.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tq_sample_locals_tail_kernel(
+// Compiled for the occupancy of the SAMPLING path (five waves per SIMD, 96 registers; the fp64 code of the global sites
+// spills ~800 registers to scratch at that cap, which the one tail workgroup can afford now that the other workgroups of
+// its grid row add the rows for it: with the tail adding all rows itself it was the last workgroup of the launch and the
+// kernel had to be built for three waves -- c2 step 0.248 -> 0.235 ms, 0.320 -> 0.288 ms in the regime of a converged fit).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void tq_sample_locals_tail_kernel(
     const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const int64_t B, const int site_begin) {
-  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 = the same from rows of 256 units
-  // with the per-AOI sites folded in), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
+  // has_prev: 0 = nothing pending, 1 = the whole tail of `prev` (cross-unit sums first; 3 = the same from rows of 64 / 256 units
+  // with the per-AOI sites folded in; 6 = the same with the rows added per group of 4096 units by the other workgroups of
+  // this grid row), 2 = gsum of `prev` is complete (all-reduced by the caller): global sites onwards
   if (blockIdx.y == 0) {
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0) {
+      // has_prev == 6: workgroup 1 + g adds the rows of group g of `prev` for the tail workgroup (one wave; the others leave)
+      if (has_prev == 6 && (int64_t)blockIdx.x <= tq_grp_count(tq_batch_units(prev)) && threadIdx.x < 64)
+        tq_group_reduce_rows(prev, (int)blockIdx.x - 1);
+      return;
+    }
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
 #ifdef TQ_MB_STAMPS  // (diagnostic build, scripts/fb_tail_time.py: how long the tail workgroup of a full-batch step lives)
@@ -571,9 +923,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
       if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
-      else if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
+      else if (has_prev == 6) {
+        if (!tq_groups_reduce_globals_body(prev, s_w, s_e) && threadIdx.x == 0) prev.elbo_out[0] = __builtin_nan("");
+      } else if (has_prev == 1) tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
       else tq_globals_from_gsum_body(prev, s_e);
       __syncthreads();
+#ifdef TQ_MB_STAMPS
+      if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[7] = __builtin_amdgcn_s_memrealtime();
+#endif
       const int64_t total = tq_num_params(prev);
       for (int64_t j = tq_aoi_base(prev) + threadIdx.x; j < total; j += 256) tq_body_adam(prev, j);
       __threadfence();
@@ -592,7 +949,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
     return;
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) tq_body_site(a, site_begin + (int)blockIdx.y - 1, i);
+  tq_sample_site_wg(a, site_begin + (int)blockIdx.y - 1, i, B);
 #ifdef TQ_MB_STAMPS
   if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0 && a.sync)
     ((uint64_t*)(a.sync + 4))[10] = __builtin_amdgcn_s_memrealtime();  // (about) the last sampling workgroup
@@ -967,6 +1324,7 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
 
 static int launch_pixel_unit(const tq_cosmos_args* a, void* stream) {
   const int64_t B = tq_batch_units(*a);
+
   const tq_ksmogn_args k = cosmos_ksmogn_args(a);
   const dim3 grid((unsigned)((B + 63) / 64)), block(64);
   hipStream_t st = (hipStream_t)stream;
@@ -1174,8 +1532,18 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
     if (int rc = tq_cosmos_tail(prev, stream)) return rc;
     prev = nullptr;
   }
+  int code = prev ? tq_prev_code(*prev) : 0;
+  {
+    // rows of 64 / 256 units: the idle workgroups of the launch's first grid row add them per group (tq_group_reduce_rows)
+    static const bool groups = [] {
+      const char* e = getenv("TAPQIR_AMD_GROUPS");
+      return !(e && e[0] == '0');
+    }();
+    const int64_t gx = (B + 255) / 256;
+    if (groups && code == 3 && prev->sync && tq_grp_count(tq_batch_units(*prev)) + 1 <= gx) code = 6;
+  }
   hipLaunchKernelGGL(tq_sample_locals_tail_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)(2 + 4 * a->K)), dim3(256), 0,
-                     (hipStream_t)stream, *a, prev ? *prev : *a, prev ? tq_prev_code(*prev) : 0, B, 0);
+                     (hipStream_t)stream, *a, prev ? *prev : *a, code, B, 0);
   if (int rc = check_launch("tq_sample_locals_tail_kernel")) return rc;
   return elbo_grads_impl(a, stream, false, tq_rows_layout(*a));
 }
@@ -1186,7 +1554,9 @@ extern "C" int64_t tq_cosmos_blk_floats(int32_t Nt, int32_t F, int32_t C, int32_
   const int64_t full = (((int64_t)Nt * F * C + 63) / 64) * ncol;                             // full-batch rows of 256 or 64 units
   const int64_t mini = ((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) * ncol;          // single-launch minibatch step: rows of 16
   const int64_t flat = tq_cosmos_nblk(B) * TQ_NGSUM_X(C, crosstalk);
-  return full > mini ? (full > flat ? full : flat) : (mini > flat ? mini : flat);
+  const int64_t grp = 4 + tq_grp_count((int64_t)Nt * F * C) * TQ_GGROW;                      // group rows behind the full-batch rows
+  const int64_t most = full > mini ? (full > flat ? full : flat) : (mini > flat ? mini : flat);
+  return most + grp;
 }
 
 

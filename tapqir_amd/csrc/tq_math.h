@@ -557,6 +557,15 @@ TQ_HD float tq_beta_grad_window_f(float x, float alpha, float beta) {
 // ANY_BOUNDARY: the saddle-point formulas for alpha, beta > 6 whatever total x (1-x) is -- for a draw near an edge
 // only ONE of the two directions is in the saddle-point regime (the other one is in a series regime); the caller
 // keeps the direction it needs (tq_beta_grad_pair_rest).
+// (does tq_beta_grad_pair_mid<false> apply?  The sampling kernels sort the draws of a workgroup by regime before they
+// evaluate anything: tq_cosmos.hip, tq_site_beta_compact)
+TQ_HD bool tq_beta_grad_pair_applies(double x, double alpha, double beta) {
+  const double total = alpha + beta;
+  const double y = 1.0 - x;
+  const double xy = x * y;
+  const double boundary = total * xy;
+  return boundary >= 2.5 && alpha > 6.0 && beta > 6.0;
+}
 template <bool ANY_BOUNDARY = false>
 TQ_HD bool tq_beta_grad_pair_mid(double x, double alpha, double beta, double* ga, double* gb) {
   const double total = alpha + beta;

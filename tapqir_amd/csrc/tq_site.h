@@ -141,7 +141,10 @@ TQ_HD void tq_gamma_site_terms(float v, float loc, float beta, float* s) {
   s[5] = 0.0f;
 }
 
-TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low, float high, float eps, float* s) {
+// dd_given: the two tq_dirichlet_grad values of the draw, dd[0] = grad(t, c1, size), dd[1] = grad(1 - t, c0, size), if the
+// caller has evaluated them already (the sampling kernels' regime compaction); nullptr: evaluated here
+TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low, float high, float eps, float* s,
+                                     const float* dd_given = nullptr) {
   const float sc = high - low;
   const float rsc = TQ_FRCP(sc);
   const float t = (y - low) * rsc;
@@ -160,6 +163,10 @@ TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low,
   // pathwise: y = low + sc * t unless clamped by rsample
   const bool clamped = (y <= low + eps * sc) || (y >= high - eps * sc);
   float dd[2] = {0.0f, 0.0f};
+  if (dd_given) {
+    dd[0] = dd_given[0];
+    dd[1] = dd_given[1];
+  } else
 #ifdef TQ_DIAG_NO_BETAGRAD
   if (false) {
 #else

@@ -128,7 +128,7 @@ class CosmosEngine:
         # minibatch steps with the lazy Adam clock run as ONE launch (include/tapqir_hip.h: tq_cosmos_minibatch_step);
         # TAPQIR_AMD_MB_FUSED=0 keeps the five-launch sequence
         self.fused_minibatch = self.pipelined_tail and os.environ.get("TAPQIR_AMD_MB_FUSED", "1") != "0"
-        self._sync = torch.zeros(32, dtype=torch.int32, device=dev)  # 4 words + room for the diagnostic stamps of a TQ_MB_STAMPS build
+        self._sync = torch.zeros(64, dtype=torch.int32, device=dev)  # TQ_SYNC_WORDS (tickets, flags; diagnostic stamps of a TQ_MB_STAMPS build)
         self._sync_value = 0
 
     # -- the library --------------------------------------------------------------------------------
