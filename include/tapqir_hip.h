@@ -200,8 +200,8 @@ typedef struct {
   float* exp_avg_sq;
   /* workspace (device) */
   float* lat;                  /* [1+4K][B]        latent draws: b, h[K], w[K], x[K], y[K] */
-  float* site;                 /* [6][(1+4K)*B]    per-site guide terms (log q, its derivatives, implicit
-                                                   reparameterisation gradients), same site order as lat */
+  float* site;                 /* [5][(1+4K)*B]    per-site guide terms (log q, its derivatives w.r.t. the concentrations,
+                                                   implicit reparameterisation gradients), same site order as lat */
   float* pix;                  /* [2^K+2+4K][B]    ll[2^K], g_b, g_gain, g_h[K], g_w[K], g_x[K], g_y[K]
                                                    (crosstalk: 1+Q more rows: ell_excess, g_alpha[Q]) */
   float* aoi_part;             /* [3][B]           per-unit d/d(bg mean, bg std) partials; row 2 = scratch */

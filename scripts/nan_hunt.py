@@ -45,7 +45,7 @@ for it in range(args.iters):
     if not ok:
         print("first non-finite at iteration", it, "elbo", elbo)
         lat = eng.lat.view(1 + 4 * K, B)
-        site = eng.site.view(6, 1 + 4 * K, B)
+        site = eng.site.view(5, 1 + 4 * K, B)  # TQ_NSITE_STORED rows: lq, d alpha (c1), grad, d c0, grad0
         pix = eng.pix.view(-1, B)
         for r in range(lat.shape[0]):
             bad = ~torch.isfinite(lat[r])
@@ -56,7 +56,7 @@ for it in range(args.iters):
                 bad = ~torch.isfinite(site[j, r])
                 if bad.any():
                     i = int(bad.nonzero()[0])
-                    print(f"  site term {j} of {names_lat[r]}: {int(bad.sum())} bad; unit {i} lat={float(lat[r, i])!r} terms={[float(site[t, r, i]) for t in range(6)]}")
+                    print(f"  site term {j} of {names_lat[r]}: {int(bad.sum())} bad; unit {i} lat={float(lat[r, i])!r} terms={[float(site[t, r, i]) for t in range(5)]}")
         for r in range(pix.shape[0]):
             bad = ~torch.isfinite(pix[r])
             if bad.any():

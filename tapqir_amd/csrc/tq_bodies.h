@@ -145,9 +145,14 @@ TQ_HD TqSiteDraw tq_site_draw(const tq_cosmos_args& a, int site, int64_t i) {
 TQ_HD void tq_site_store(const tq_cosmos_args& a, int site, const TqSiteDraw& d, const float* terms) {
   const int64_t NS = (int64_t)(1 + 4 * a.K) * tq_batch_units(a);
   a.lat[d.t] = d.val;
-#pragma unroll
-  for (int j = 0; j < TQ_NSITE_TERMS; ++j)
-    if (j < 5 || site > a.K) a.site[(int64_t)j * NS + d.t] = terms[j];  // Gamma sites have five terms: slot 5 is never read
+  // stored rows (tq_site.h: TQ_NSITE_STORED): log q, d lq/d alpha (d c1), implicit gradient; AffineBeta: + d lq/d c0, second gradient
+  a.site[d.t] = terms[0];
+  a.site[NS + d.t] = terms[2];
+  a.site[2 * NS + d.t] = terms[4];
+  if (site > a.K) {
+    a.site[3 * NS + d.t] = terms[3];
+    a.site[4 * NS + d.t] = terms[5];
+  }
 }
 TQ_HD void tq_body_site(const tq_cosmos_args& a, int site, int64_t i) {
   const TqSiteDraw d = tq_site_draw(a, site, i);
@@ -212,12 +217,12 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
   }
   const int64_t NS = (int64_t)(1 + 4 * K) * B;
 #pragma unroll
-  for (int j = 0; j < TQ_NSITE_TERMS; ++j) {
+  for (int j = 0; j < TQ_NSITE_STORED; ++j) {
     const float* sj = a.site + (int64_t)j * NS;
-    in.sb[j] = j < 5 ? sj[i] : 0.0f;  // (Gamma sites: five terms)
+    if (j < 3) in.sb[j] = sj[i];  // (Gamma sites: three stored terms)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      in.sh[k][j] = j < 5 ? sj[(int64_t)(1 + k) * B + i] : 0.0f;
+      if (j < 3) in.sh[k][j] = sj[(int64_t)(1 + k) * B + i];
       in.sw[k][j] = sj[(int64_t)(1 + K + k) * B + i];
       in.sx[k][j] = sj[(int64_t)(1 + 2 * K + k) * B + i];
       in.sy[k][j] = sj[(int64_t)(1 + 3 * K + k) * B + i];
@@ -265,23 +270,32 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
     a.aoi_part[B + i] = masked ? 0.0f : out.g_bsl;
   }
 
-  const int nq = tq_num_gsum(a);
-  for (int j = 0; j < nq; ++j) part[j] = 0.0f;
-  if (!masked) {
-    part[TQ_GS_GAIN] = g_gain;
-    part[TQ_GS_CS] = out.d_cs;
-    part[TQ_GS_ELBO] = out.elbo;
-    part[TQ_GS_Q0 + 3 * ix.c + 0] = out.d_rho;
-    part[TQ_GS_Q0 + 3 * ix.c + 1] = out.d_a;
-    part[TQ_GS_Q0 + 3 * ix.c + 2] = out.d_c;
-    if (a.crosstalk) {
-      // rows after the cosmos block of pix: [ell_excess][g_alpha[q]] (tq_xtalk.h).  in.ll held the per-dye
-      // MARGINAL likelihoods, so every dye's Dice sum contains E[ll]: remove the copies beyond the first
-      const int64_t x0 = (int64_t)(M + 2 + 4 * K) * B;
-      part[TQ_GS_ELBO] -= in.wu * a.pix[x0 + i];
-      for (int q = 0; q < a.C; ++q) part[TQ_GS_ALPHA0(a.C) + q * a.C + ix.c] = a.pix[x0 + (int64_t)(1 + q) * B + i];
+  // Every entry is assigned with compile-time indices and selected VALUES: indexed by the run-time channel (or written
+  // under a run-time condition, which the compiler turns back into an indexed store) the caller's array went to scratch
+  // memory -- 64 B per lane written and read back in the fused pixel + per-unit kernel.
+  part[TQ_GS_GAIN] = masked ? 0.0f : g_gain;
+  part[TQ_GS_CS] = masked ? 0.0f : out.d_cs;
+  float elbo_u = out.elbo;
+#pragma unroll
+  for (int q = 0; q < TQ_MAXQ; ++q) {
+    const bool mine = !masked && q == ix.c;
+    part[TQ_GS_Q0 + 3 * q + 0] = mine ? out.d_rho : 0.0f;
+    part[TQ_GS_Q0 + 3 * q + 1] = mine ? out.d_a : 0.0f;
+    part[TQ_GS_Q0 + 3 * q + 2] = mine ? out.d_c : 0.0f;
+  }
+  if (a.crosstalk) {
+    // rows after the cosmos block of pix: [ell_excess][g_alpha[q]] (tq_xtalk.h).  in.ll held the per-dye
+    // MARGINAL likelihoods, so every dye's Dice sum contains E[ll]: remove the copies beyond the first
+    const int64_t x0 = (int64_t)(M + 2 + 4 * K) * B;
+    elbo_u -= in.wu * a.pix[x0 + i];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // (the crosstalk model is Q = C = 2: the alpha block follows the two dyes' entries)
+      const float ga = a.pix[x0 + (int64_t)(1 + q) * B + i];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) part[TQ_GS_ALPHA0(2) + q * 2 + c] = (!masked && c == ix.c) ? ga : 0.0f;
     }
   }
+  part[TQ_GS_ELBO] = masked ? 0.0f : elbo_u;
 }
 
 // ---- per-AOI: finish d/d(background_mean_loc, background_std_loc) given the frame sums --------------------

@@ -125,6 +125,32 @@ TQ_HD void tq_beta_logpdf(float t, float c1, float c0, float* lp, float* d_t, fl
 //   AffineBeta(mean, size, low, high), draw y = low + sc*t (clamped):
 //     s[0] = log q(y)  s[1] = d lq/d y  s[2] = d lq/d c1  s[3] = d lq/d c0  s[4] = d y/d c1  s[5] = d y/d c0
 #define TQ_NSITE_TERMS 6
+// What the sampling kernel hands to the per-unit phase through the step workspace (`site`, TQ_NSITE_STORED rows): the terms
+// that cost transcendental series or regime code -- log q, d lq/d alpha (d c1, d c0), the implicit gradients.  d lq/d v,
+// d lq/d beta (Gamma) and d lq/d y (AffineBeta) are one or two reciprocals from the draw and the parameters the per-unit
+// phase holds anyway, and are rebuilt there (48 B per unit less written by one launch and read by the next at K = 2).
+//   stored rows: 0 = s[0], 1 = s[2], 2 = s[4], and for AffineBeta sites 3 = s[3], 4 = s[5]
+#define TQ_NSITE_STORED 5
+TQ_HD void tq_gamma_terms_expand(const float* c, float v, float loc, float beta, float* s) {
+  s[0] = c[0];
+  s[1] = (loc * beta - 1.0f) * TQ_FRCP(v) - beta;  // d lq / d v   (tq_gamma_logpdf)
+  s[2] = c[1];
+  s[3] = loc - v;                                  // d lq / d beta
+  s[4] = c[2];
+  s[5] = 0.0f;
+}
+TQ_HD void tq_affine_beta_terms_expand(const float* c, float y, float mean, float size, float low, float high, float* s) {
+  const float rsc = TQ_FRCP(high - low);
+  const float t = (y - low) * rsc;
+  const float c1 = size * (mean - low) * rsc;
+  const float c0 = size * (high - mean) * rsc;
+  s[0] = c[0];
+  s[1] = ((c1 - 1.0f) * TQ_FRCP(t) - (c0 - 1.0f) * TQ_FRCP(1.0f - t)) * rsc;  // d lq / d y   (tq_beta_logpdf, tq_affine_beta_site_terms)
+  s[2] = c[1];
+  s[3] = c[3];
+  s[4] = c[2];
+  s[5] = c[4];
+}
 
 TQ_HD void tq_gamma_site_terms(float v, float loc, float beta, float* s) {
   float lq, d_v, d_alpha, d_beta;
@@ -214,8 +240,8 @@ struct TqUnitIn {
   float b, h[K], w[K], x[K], y[K];  // latent draws
   float ll[1 << K];        // unweighted pixel log-likelihood per combination
   float gb, gh[K], gw[K], gx[K], gy[K];  // pathwise pixel gradients, already times w_u W(m)
-  float sb[TQ_NSITE_TERMS];                 // guide-site terms of b
-  float sh[K][TQ_NSITE_TERMS], sw[K][TQ_NSITE_TERMS], sx[K][TQ_NSITE_TERMS], sy[K][TQ_NSITE_TERMS];
+  float sb[3];                              // stored guide-site terms of b (TQ_NSITE_STORED rows; Gamma sites: three)
+  float sh[K][3], sw[K][TQ_NSITE_STORED], sx[K][TQ_NSITE_STORED], sy[K][TQ_NSITE_STORED];
   float wu;                // plate scale * mask
   int on;                  // is_ontarget
   int q;                   // dye / channel index
@@ -332,8 +358,11 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
     const float hs = C.height_std, rhs2 = TQ_FRCP(hs * hs);
     const float lp_h = TQ_LN2 - TQ_FLOG(hs) - TQ_LN_SQRT_2PI - 0.5f * in.h[k] * in.h[k] * rhs2;
     const float e_h = in.gh[k] + wq * (-in.h[k] * rhs2);
-    tq_gamma_site_chain(in.sh[k], in.h[k], hl, hb, e_h, wq, &out->g[TQ_ROW(TQ_P_HLOC, k, K)],
-                        &out->g[TQ_ROW(TQ_P_HBETA, k, K)]);
+    {
+      float s[TQ_NSITE_TERMS];
+      tq_gamma_terms_expand(in.sh[k], in.h[k], hl, hb, s);
+      tq_gamma_site_chain(s, in.h[k], hl, hb, e_h, wq, &out->g[TQ_ROW(TQ_P_HLOC, k, K)], &out->g[TQ_ROW(TQ_P_HBETA, k, K)]);
+    }
     float t_k = lp_h - in.sh[k][0];
     // width: prior uniform on (w_lo, w_hi), guide AffineBeta(w_mean, w_size, w_lo, w_hi)
     {
@@ -342,7 +371,9 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
       const float mean = lo + (hi - lo) * sg;
       const float ex = TQ_FEXP(in.u[TQ_ROW(TQ_P_WSIZE, k, K)]);
       float d_mean, d_size;
-      tq_affine_beta_site_chain(in.sw[k], mean, 2.0f + ex, C.w_lo, C.w_hi, in.gw[k], wq, &d_mean, &d_size);
+      float s[TQ_NSITE_TERMS];
+      tq_affine_beta_terms_expand(in.sw[k], in.w[k], mean, 2.0f + ex, C.w_lo, C.w_hi, s);
+      tq_affine_beta_site_chain(s, mean, 2.0f + ex, C.w_lo, C.w_hi, in.gw[k], wq, &d_mean, &d_size);
       out->g[TQ_ROW(TQ_P_WMEAN, k, K)] = d_mean * (hi - lo) * sg * (1.0f - sg);
       out->g[TQ_ROW(TQ_P_WSIZE, k, K)] = d_size * ex;
       t_k += -TQ_FLOG(w_sc) - in.sw[k][0];
@@ -357,9 +388,12 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
       float d_mean, d_size_x, d_size_y;
       const float e_x = in.gx[k] + wu * dS[k] * dsx[k];
       const float e_y = in.gy[k] + wu * dS[k] * dsy[k];
-      tq_affine_beta_site_chain(in.sx[k], lo + (hi - lo) * sgx, size, -H, H, e_x, wq, &d_mean, &d_size_x);
+      float s[TQ_NSITE_TERMS];
+      tq_affine_beta_terms_expand(in.sx[k], in.x[k], lo + (hi - lo) * sgx, size, -H, H, s);
+      tq_affine_beta_site_chain(s, lo + (hi - lo) * sgx, size, -H, H, e_x, wq, &d_mean, &d_size_x);
       out->g[TQ_ROW(TQ_P_XMEAN, k, K)] = d_mean * (hi - lo) * sgx * (1.0f - sgx);
-      tq_affine_beta_site_chain(in.sy[k], lo + (hi - lo) * sgy, size, -H, H, e_y, wq, &d_mean, &d_size_y);
+      tq_affine_beta_terms_expand(in.sy[k], in.y[k], lo + (hi - lo) * sgy, size, -H, H, s);
+      tq_affine_beta_site_chain(s, lo + (hi - lo) * sgy, size, -H, H, e_y, wq, &d_mean, &d_size_y);
       out->g[TQ_ROW(TQ_P_YMEAN, k, K)] = d_mean * (hi - lo) * sgy * (1.0f - sgy);
       t_k -= in.sx[k][0] + in.sy[k][0];
       out->g[TQ_ROW(TQ_P_SIZE, k, K)] = (d_size_x + d_size_y) * ex;
@@ -401,7 +435,9 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
     out->g_bsl = wu * (d_alpha * -2.0f * a0 + d_beta * -2.0f * r0);
     const float bl = TQ_FEXP(in.u[TQ_ROW_BLOC(K)]), bb = TQ_FEXP(in.u[TQ_ROW_BBETA(K)]);
     const float e_b = in.gb + wu * d_v;
-    tq_gamma_site_chain(in.sb, in.b, bl, bb, e_b, wu, &out->g[TQ_ROW_BLOC(K)], &out->g[TQ_ROW_BBETA(K)]);
+    float s[TQ_NSITE_TERMS];
+    tq_gamma_terms_expand(in.sb, in.b, bl, bb, s);
+    tq_gamma_site_chain(s, in.b, bl, bb, e_b, wu, &out->g[TQ_ROW_BLOC(K)], &out->g[TQ_ROW_BBETA(K)]);
     Esum += lp_b - in.sb[0];
   }
 

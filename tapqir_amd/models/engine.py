@@ -247,7 +247,7 @@ class CosmosEngine:
         B = nb * fb * self.C
         dev, f32 = self.device, torch.float32
         self.lat = torch.zeros((1 + 4 * K) * B, dtype=f32, device=dev)
-        self.site = torch.zeros(6 * (1 + 4 * K) * B, dtype=f32, device=dev)
+        self.site = torch.zeros(int(os.environ.get("TAPQIR_AMD_SITE_ROWS", 5)) * (1 + 4 * K) * B, dtype=f32, device=dev)  # TQ_NSITE_STORED rows (the switch: A/B runs against older builds of the library)
         self.pix = torch.zeros((M + 2 + 4 * K + (1 + self.C if self.crosstalk else 0)) * B, dtype=f32, device=dev)
         self.aoi_part = torch.zeros(3 * B, dtype=f32, device=dev)
         nblk = (B + 255) // 256
