@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X nominal HBM3E bandwidth (MI355X_MICROARCH.md); ~
 
 # per-GPU shards of the BASELINE.json configs: (model, K, P, AOIs per GPU, frames, channels, ranks at which it IS the config)
 CONFIGS = {
+    "c1": ("cosmos", 1, 14, 50, 100, 1, 1),  # the reference's own CPU-runnable case (plumbing; 5 000 units: launch-bound on a GPU)
     "c2": ("cosmos", 2, 14, 400, 1000, 1, 1),
     "c3": ("cosmos", 2, 14, 400, 4000, 1, 8),
     "c4": ("crosstalk", 2, 14, 400, 1000, 2, 1),
@@ -61,21 +62,55 @@ def step_bytes_per_unit(K, P):
     return 4 * P * P + 8 + 6 * 4 * (8 * K + 2)
 
 
-def pmc_traffic(K, P, units, backward):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 correction applied; profiles/*_pmc_traffic.json says how).  PMC collection cannot run
-    inside this process, so the figure is the measured one for this exact kernel and shape, else None."""
-    prof = os.path.join(ROOT, "profiles")
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+PROFILE_ROUNDS = ("r03", "r02", "r01")
+
+
+def _profile_json(suffix):
+    """Newest committed profiles/rNN_<suffix> (written by scripts/gpu_r03_profiles.sh from rocprofv3 runs of THIS script)."""
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{suffix}")
         try:
-            d = json.load(open(os.path.join(prof, name)))
+            return json.load(open(path)), f"profiles/{rnd}_{suffix}"
         except OSError:
             continue
-        if (d.get("K"), d.get("P"), d.get("units")) != (K, P, units):
-            continue
-        for kname, k in d["kernels"].items():
-            if kname.endswith(f"<{K}, {P}, {'true' if backward else 'false'}>"):
-                return k["traffic_bytes"], name
+    return None, None
+
+
+def pmc_traffic(K, P, units, backward):
+    """HBM bytes per launch of the stand-alone log-prob kernel from the committed PMC passes (rocprofv3 FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 correction applied; profiles/*_pmc_traffic.json says how).  PMC collection cannot
+    run inside this process, so the figure is the measured one for this exact kernel and shape, else None."""
+    d, name = _profile_json("pmc_traffic.json")
+    if d is None or (d.get("K"), d.get("P"), d.get("units")) != (K, P, units):
+        return None, None
+    for kname, k in d["kernels"].items():
+        if kname.endswith(f"<{K}, {P}, {'true' if backward else 'false'}>"):
+            return k["traffic_bytes"], name
+    return None, None
+
+
+def step_traffic(cfg, units):
+    """Per-launch HBM bytes of every kernel of one STEP of config `cfg`, and their sum, from the committed PMC passes over
+    `bench.py --quick` (profiles/*_pmc_step_traffic.json, scripts/make_step_traffic.py).  None if not collected for this
+    config and size."""
+    d, name = _profile_json("pmc_step_traffic.json")
+    if d is None:
+        return None, None
+    c = d["configs"].get(cfg)
+    if not c or c.get("units") != units:
+        return None, None
+    return c, name
+
+
+def trace_duration(cfg, kernel_substr):
+    """Average duration (ms) of a kernel in the committed rocprofv3 kernel trace of `bench.py` for config `cfg`
+    (profiles/*_kernel_trace.json, scripts/gpu_r03_profiles.sh), else None."""
+    d, name = _profile_json("kernel_trace.json")
+    if d is None:
+        return None, None
+    for k, v in d.get(cfg, {}).items():
+        if kernel_substr in k:
+            return v["avg_us"] * 1e-3, name
     return None, None
 
 
@@ -84,7 +119,7 @@ def pmc_valu_issue(kernel_tag, units, avg_launch_s):
     rocprofv3 --pmc runs, scripts/gpu_step_pmc.sh): the kernels whose HBM fraction is low are bound by instruction issue,
     and this is the roof they are at.  `busy_at_nominal_clock` prices the measured launch of THIS run at 2.4 GHz."""
     prof = os.path.join(ROOT, "profiles")
-    for name in ("r02_pmc_valu.json",):
+    for name in ("r03_pmc_valu.json", "r02_pmc_valu.json"):
         try:
             d = json.load(open(os.path.join(prof, name)))
         except OSError:
@@ -183,11 +218,21 @@ class Runner:
     def __init__(self, use_dist, dev):
         self.use_dist, self.dev = use_dist, dev
         self.allreduce = None
+        self.backend = "none"
         if use_dist:
             import torch.distributed as dist
 
-            # left in flight: the engine overlaps it with the next step's local guide sampling (full-batch steps)
-            self.allreduce = lambda t: dist.all_reduce(t, async_op=True)
+            if os.environ.get("TAPQIR_AMD_RCCL_DIRECT", "1") != "0":
+                # ncclAllReduce of RCCL on the launch stream itself (tapqir_amd/rccl.py): stream order is the only dependency
+                from tapqir_amd.rccl import RcclDirect
+
+                self.allreduce = RcclDirect(device=dev)
+                self.backend = RcclDirect.backend
+            else:
+                # torch's process group (its own stream), left in flight: the engine overlaps it with the next step's local
+                # guide sampling (full-batch steps)
+                self.allreduce = lambda t: dist.all_reduce(t, async_op=True)
+                self.backend = dist.get_backend()
 
     def run(self, eng, n, ndx=None, fdx=None):
         for _ in range(n):
@@ -385,6 +430,10 @@ def time_fused_kernel(eng, launches):
 
 
 def roofline_block(pb, ms_per_step, dev):
+    """`roofline` of the bench line: the DOMINANT kernel of the timed step -- the fused pixel + per-unit launch where the
+    step runs it (c1 / c2 / c3), else the log-prob (pixel) kernel -- at its algorithmic bytes, with its duration measured here
+    (HIP events on the launch stream) next to the one in the committed rocprofv3 trace of this script, its PMC traffic, the
+    traffic of the whole step and the stand-alone log-prob kernel as sub-objects."""
     import torch
 
     eng, K, P = pb.eng, pb.K, pb.P
@@ -405,33 +454,57 @@ def roofline_block(pb, ms_per_step, dev):
     traffic, tsrc = (pmc_traffic(K, P, units, True) if (pb.offsets == "sim" and not eng.crosstalk) else (None, None))
     sb = step_bytes_per_unit(K, P)
     tot_units = pb.N * pb.F * pb.C
-    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-           "traffic": traffic,
-           "traffic_unit": f"bytes/launch (PMC, profiles/{tsrc}); algorithmic = bytes_per_unit x units_per_launch",
-           "kernel": kernel, "bytes_per_unit": bpu, "units_per_launch": units, "avg_launch_ms": t_fb * 1e3,
-           "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": units * bpu / t_f / 1e9,
-                            "frac": units * bpu / t_f / 1e9 / HBM_PEAK_GBS},
-           "whole_step": {"bytes_per_unit": sb, "achieved": tot_units * sb / (ms_per_step * 1e-3) / 1e9,
-                          "frac": tot_units * sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    logprob = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+               "traffic": traffic,
+               "traffic_unit": f"bytes/launch (PMC, {tsrc}); algorithmic = bytes_per_unit x units_per_launch",
+               "kernel": kernel, "bytes_per_unit": bpu, "units_per_launch": units, "avg_launch_ms": t_fb * 1e3,
+               "timing": "stand-alone launches of the kernel, HIP events on the launch stream",
+               "forward_only": {"avg_launch_ms": t_f * 1e3, "achieved": units * bpu / t_f / 1e9,
+                                "frac": units * bpu / t_f / 1e9 / HBM_PEAK_GBS}}
     if not eng.crosstalk:
         bb = bwd_bytes_per_unit(K, P)
-        out["with_gradient_outputs"] = {"bytes_per_unit": bb, "achieved": units * bb / t_fb / 1e9,
-                                        "frac": units * bb / t_fb / 1e9 / HBM_PEAK_GBS,
-                                        "note": "bytes_per_unit + K m_probs logits read + (2+4K) gradient rows written"}
-    if getattr(eng, "fuse_unit", False) and eng._fusable():
-        # what the timed steps actually launch: pixel kernel + per-unit terms + Adam as one kernel, whose algorithmic
-        # bytes are those of the whole step (tile + target position + read/write of every local parameter and moment)
+        logprob["with_gradient_outputs"] = {"bytes_per_unit": bb, "achieved": units * bb / t_fb / 1e9,
+                                            "frac": units * bb / t_fb / 1e9 / HBM_PEAK_GBS,
+                                            "note": "bytes_per_unit + K m_probs logits read + (2+4K) gradient rows written"}
+    cfg_tag = pb.cfg if (pb.N, pb.F) == CONFIGS[pb.cfg][3:5] and pb.offsets == "sim" else None
+    st, stsrc = step_traffic(cfg_tag, tot_units) if cfg_tag else (None, None)
+    fused = bool(getattr(eng, "fuse_unit", False)) and eng._fusable()
+    if fused:
+        # what the timed steps launch: pixel kernel + per-unit terms + Adam as one kernel, whose algorithmic bytes are those
+        # of the whole step (tile + target position + read/write of every local parameter and moment)
         t_pu = time_fused_kernel(eng, 10)
-        out["step_kernel"] = {"kernel": "tq_pixel_unit_kernel<K,P> (the pixel kernel above + per-unit ELBO terms, gradients and "
-                                        "Adam of the same 64 units, one launch; chosen over two launches by timing both on "
-                                        f"this box: {[round(t, 4) for t in getattr(eng, 'step_times_ms', [])]} ms per step)",
-                              "timing": "HIP events: (launches x [sampling, this kernel]) - (launches x sampling), each an uninterrupted "
-                                        "sequence on the launch stream.  The difference also contains what this kernel costs the sampling "
-                                        "launch that follows it (86 MB of parameter writes still draining): the kernel-only duration in the "
-                                        "rocprofv3 trace (profiles/r02_kernel_trace_summary.txt) is ~8 % shorter, and the sampling launch of a "
-                                        "step is ~12 us longer there than back to back with itself",
-                              "bytes_per_unit": sb, "units_per_launch": tot_units, "avg_launch_ms": t_pu * 1e3,
-                              "achieved": tot_units * sb / t_pu / 1e9, "frac": tot_units * sb / t_pu / 1e9 / HBM_PEAK_GBS}
+        tr, trsrc = trace_duration(cfg_tag, "tq_pixel_unit_kernel") if cfg_tag else (None, None)
+        out = {"bound": "hbm", "achieved": tot_units * sb / t_pu / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": tot_units * sb / t_pu / 1e9 / HBM_PEAK_GBS,
+               "kernel": "tq_pixel_unit_kernel<K,P>: the dominant launch of the timed step (render + log-prob + pathwise grads of a "
+                         "tile of 64 units, then the per-unit ELBO terms, gradients and Adam of the same units in the same wave; "
+                         f"chosen over two launches by timing both on this box: {[round(t, 4) for t in getattr(eng, 'step_times_ms', [])]} ms per step)",
+               "bytes_per_unit": sb, "units_per_launch": tot_units, "avg_launch_ms": t_pu * 1e3,
+               "timing": "HIP events on the launch stream: (launches x [sampling, this kernel]) - (launches x sampling), each an "
+                         "uninterrupted sequence, so that the kernel is timed between the launches it runs between in a step",
+               "trace": {"avg_launch_ms": tr, "source": trsrc,
+                         "note": "kernel-only duration of the same kernel in the committed rocprofv3 --kernel-trace of this script"},
+               "traffic": (st["kernels"].get("tq_pixel_unit_kernel", {}).get("traffic_bytes") if st else None),
+               "traffic_unit": f"bytes/launch of this kernel (PMC FETCH_SIZE x 2 KiB + WRITE_SIZE KiB in separate passes over this script, {stsrc}); "
+                               "algorithmic = bytes_per_unit x units_per_launch"}
+    else:
+        out = dict(logprob)
+        out["kernel"] = "dominant launch of the timed step: " + kernel
+        if st:
+            k0 = next((v for k, v in st["kernels"].items() if "ksmogn" in k or "xtalk" in k), None)
+            if k0 and traffic is None:
+                out["traffic"], out["traffic_unit"] = k0["traffic_bytes"], f"bytes/launch (PMC passes over this script, {stsrc})"
+    out["logprob_kernel"] = logprob
+    out["whole_step"] = {"bytes_per_unit": sb, "achieved": tot_units * sb / (ms_per_step * 1e-3) / 1e9,
+                         "frac": tot_units * sb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "algorithmic bytes of the step (tile, target position, every local parameter and Adam moment read and "
+                                 "written once) over the driver-timed step"}
+    if st:
+        out["step_traffic"] = {"bytes": st["step_traffic_bytes"], "algorithmic": tot_units * sb,
+                               "ratio": st["step_traffic_bytes"] / (tot_units * sb), "source": stsrc,
+                               "per_kernel": {k: v["traffic_bytes"] for k, v in st["kernels"].items()},
+                               "note": "HBM bytes of ALL launches of one step (PMC) against the step's algorithmic bytes: the excess is the "
+                                       "hand-off of the guide draws and site terms between the two launches"}
     tag = "c4" if eng.crosstalk else ("hist" if eng.O > 1 else ("c5" if (K, P) == (3, 20) else ("c2" if (K, P) == (2, 14) else None)))
     vi = pmc_valu_issue(tag, units, t_fb) if tag else None
     if vi:
@@ -446,8 +519,8 @@ def roofline_block(pb, ms_per_step, dev):
                                  "frac": units * per_unit / t_fb / 1e12 / peak}
     bw = measured_copy_bandwidth(dev)
     out["peak_measured_copy"] = bw
-    out["frac_of_measured_copy"] = ach / bw
-    out["forward_only"]["frac_of_measured_copy"] = out["forward_only"]["achieved"] / bw
+    out["frac_of_measured_copy"] = out["achieved"] / bw
+    logprob["forward_only"]["frac_of_measured_copy"] = logprob["forward_only"]["achieved"] / bw
     return out
 
 
@@ -512,6 +585,10 @@ def worker(args):
     cfg = "c2" if args.config == "auto" else args.config
     pb = Problem(cfg, rank, world, dev, offsets=args.offsets, aois=args.aois, frames=args.frames)
     eng = pb.eng
+    if args.pre_steps > 0:
+        # untimed steps of fitting before anything is measured (profiling runs of the trained-parameter regime)
+        runner.run(eng, args.pre_steps)
+        runner.barrier()
     h = headline(pb, runner, args)
     # host side of a step (outside the timed region): time to ENQUEUE 20 steps on an idle queue; if it approaches
     # ms_per_step the launch path, not the GPU, sets the pace
@@ -526,13 +603,13 @@ def worker(args):
     out = {
         "metric": f"{pb.model} SVI AOI-frames/s (= ELBO steps/s x nb x fb), K={pb.K} P={pb.P} full batch",
         "value": h["value"], "unit": "AOI-frames/s", "n_gpus": world,
-        "rccl_ranks": (dist.get_world_size() if use_dist else 1), "backend": (dist.get_backend() if use_dist else "none"),
+        "rccl_ranks": (dist.get_world_size() if use_dist else 1), "backend": runner.backend,
         "steps": args.steps, "warmup": args.warmup, "blocks": args.blocks,
         "ms_per_step": h["ms_per_step"], "block_ms_per_step": h["block_ms_per_step"],
         "per_rank_ms_per_step": h["per_rank_ms_per_step"], "host_enqueue_ms_per_step": host_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": h["workload"], "baseline_config": cfg, "nb": pb.N, "fb": pb.F,
-                   "aoi_sharding": f"{world} x {pb.N} AOIs"},
+                   "aoi_sharding": f"{world} x {pb.N} AOIs", "pre_steps": args.pre_steps},
         "elbo_steps_per_sec": h["elbo_steps_per_sec"], "final_elbo": h["final_elbo"],
     }
 
@@ -613,6 +690,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--quick", action="store_true", help="headline only (no minibatch / roofline / CPU legs)")
     ap.add_argument("--trained-steps", type=int, default=4000, help="steps before the trained-regime leg (0 = skip)")
+    ap.add_argument("--pre-steps", type=int, default=0, help="untimed full-batch steps before the headline (profiling the trained regime)")
     ap.add_argument("--offsets", default="sim", choices=["sim", "hist"])
     ap.add_argument("--model", default=None, choices=["cosmos", "crosstalk"], help="crosstalk = --config c4")
     ap.add_argument("--force-dist", action="store_true",

@@ -91,6 +91,10 @@ typedef struct {
   int32_t pixel_mode;          /* backward pass on the interleaved layout (K <= 2, one offset): 1 = persistent waves that walk
                                   over the tiles with every global read an LDS-DMA request, 0 = one wave per tile.  Same
                                   results; which is faster depends on the box, so the host times both once */
+  int32_t images_by_slot;      /* 1: `images` holds only the AOIs of THIS batch, AOI number ai of the batch at
+                                  images[ai * F * C * P * P] (a window of a data set that does not fit the device: the host
+                                  streams the AOIs of a batch in, dataset.py:140-151 does the same per minibatch); every other
+                                  array stays dataset-indexed.  Gathered batches (ndx given) of the 16-lane kernel */
 } tq_ksmogn_args;
 
 int tq_ksmogn_log_prob(const tq_ksmogn_args* a, void* stream);
@@ -260,6 +264,8 @@ typedef struct {
                                   launch leaves the counters re-armed. */
   int32_t sync_value;          /* value the flag takes in this launch: any value different from the previous launch's on the
                                   same `sync` words (a launch counter of the host) */
+  int32_t images_by_slot;      /* 1: `images` is a window holding the AOIs of this batch in batch order (tq_ksmogn_args.images_by_slot):
+                                  data sets larger than the device memory, whose AOIs the host streams in group by group */
 } tq_cosmos_args;
 
 #define TQ_TAIL_AUTO 0

@@ -11,6 +11,6 @@ for round in 1 2 3; do
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 r=d['roofline']
-print('$cfg', 'step_ms=%.4f'%d['ms_per_step'], 'mb_ms=%.4f'%d['minibatch_10x512']['ms_per_step'], 'trained=%.4f'%d.get('trained_regime',{}).get('ms_per_step',float('nan')), 'steps both ways', getattr(sys.modules[__name__],'x',None) or [v for k,v in r.items() if k=='step_kernel'] and r['step_kernel']['kernel'][-45:])"
+print('$cfg', 'step_ms=%.4f'%d['ms_per_step'], 'mb_ms=%.4f'%d['minibatch_10x512']['ms_per_step'], 'trained=%.4f'%d.get('trained_regime',{}).get('ms_per_step',float('nan')), 'dominant_ms=%.4f'%r['avg_launch_ms'])"
   done
 done

@@ -36,7 +36,7 @@ class KsmognArgs(C.Structure):
         ("nb", C.c_int32), ("fb", C.c_int32), ("C", C.c_int32), ("F", C.c_int32),
         ("P", C.c_int32), ("K", C.c_int32), ("O", C.c_int32),
         ("nb_full", C.c_int32), ("il_min_units", C.c_int32),
-        ("scale", C.c_float), ("pixel_mode", C.c_int32),
+        ("scale", C.c_float), ("pixel_mode", C.c_int32), ("images_by_slot", C.c_int32),
     ]
 
 
@@ -64,6 +64,7 @@ class CosmosArgs(C.Structure):
         ("seed", C.c_uint64), ("step", C.c_uint32),
         ("last_step", C.c_void_p), ("beta1_d", C.c_double), ("beta2_d", C.c_double),
         ("pixel_mode", C.c_int32), ("tail_kind", C.c_int32), ("sync", C.c_void_p), ("sync_value", C.c_int32),
+        ("images_by_slot", C.c_int32),
     ]
 
 

@@ -519,8 +519,8 @@ __host__ __device__ __forceinline__ int64_t tq_grp_count(int64_t B) { return (B 
 // group rows follow the rows in blk_part (16-byte aligned)
 __host__ __device__ __forceinline__ int64_t tq_grp_base(int64_t nrows, int ncol) { return ((nrows * ncol + 3) / 4) * 4; }
 
-// one wave: rows of group g of step `a` -> group row g (published)
-__device__ __forceinline__ void tq_group_reduce_rows(const tq_cosmos_args& a, const int g) {
+// one wave: rows of group g of step `a` -> group row g (published); returns (lane 0) how many groups had been published before
+__device__ __forceinline__ int tq_group_reduce_rows(const tq_cosmos_args& a, const int g) {
   const int lane = threadIdx.x & 63;
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
   const int64_t B = tq_batch_units(a);
@@ -564,7 +564,9 @@ __device__ __forceinline__ void tq_group_reduce_rows(const tq_cosmos_args& a, co
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group row has left
-  if (lane == 0) __hip_atomic_fetch_add(a.sync + TQ_SYNC_GROUPS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(a.sync + TQ_SYNC_GROUPS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return ticket;
 }
 
 // Fused pixel + per-unit kernel of full-batch steps (pixel_mode = TQ_PIXEL_FUSED_UNIT): a wave renders its tile of 64
@@ -753,10 +755,12 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
   tq_globals_from_gsum_body(a, s_e);
 }
 
-// Tail of a step from the group rows that the reducer workgroups of the same launch publish (ONE workgroup of 256 threads):
-// waits for them, then per-AOI sites from the one or two groups that overlap the AOI, cross-unit sums, global sites and
-// the total ELBO.  Returns false after ~2 s without the reducers (never observed; the caller leaves a NaN loss).
-__device__ __forceinline__ bool tq_groups_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+// Sums of a step from the group rows that other workgroups publish (ONE workgroup of 256 threads): WAIT: polls the counter of
+// published groups first (the tail workgroup inside a sampling launch; returns false after ~2 s without them: never
+// observed, the caller leaves a NaN loss) -- else the caller knows they are all there (the last workgroup of
+// tq_group_sums_kernel).  Then per-AOI sites from the one or two groups that overlap the AOI and the cross-unit sums -> gsum.
+template <bool WAIT>
+__device__ __forceinline__ bool tq_groups_sums_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM]) {
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
   const int64_t B = tq_batch_units(a);
   const uint32_t UPR = (uint32_t)tq_rows_upr(a);
@@ -767,13 +771,15 @@ __device__ __forceinline__ bool tq_groups_reduce_globals_body(const tq_cosmos_ar
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ int s_ok;
   if (threadIdx.x == 0) {
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     int ok = 1;
-    while (__hip_atomic_load(a.sync + TQ_SYNC_GROUPS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngroups) {
-      __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
-        ok = 0;
-        break;
+    if (WAIT) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(a.sync + TQ_SYNC_GROUPS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngroups) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+          ok = 0;
+          break;
+        }
       }
     }
     __hip_atomic_store(a.sync + TQ_SYNC_GROUPS, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
@@ -820,6 +826,11 @@ __device__ __forceinline__ bool tq_groups_reduce_globals_body(const tq_cosmos_ar
   }
   __syncthreads();
   if (threadIdx.x < nq) a.gsum[threadIdx.x] = s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+  return true;
+}
+// ... and the global sites + total ELBO (the tail workgroup of a sampling launch)
+__device__ __forceinline__ bool tq_groups_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+  if (!tq_groups_sums_body<true>(a, s_w)) return false;
   __threadfence_block();
   __syncthreads();
 #ifdef TQ_MB_STAMPS
@@ -828,6 +839,23 @@ __device__ __forceinline__ bool tq_groups_reduce_globals_body(const tq_cosmos_ar
   tq_globals_from_gsum_body(a, s_e);
   return true;
 }
+
+// AOI-sharded full-batch steps (and tq_cosmos_tail): rows -> per-AOI sites and gsum, what the all-reduce needs.  Workgroup g
+// adds the rows of group g (one wave, one round trip) and publishes the group row; the workgroup whose ticket is the last
+// one finishes the per-AOI sites and the cross-unit sums from the U / 4096 group rows (tq_rows_sums_kernel, one wave per AOI
+// and a last workgroup that walked all 6250 rows, took 38 us at c2 -- on the critical path of every sharded step).
+__global__ __launch_bounds__(256) void tq_group_sums_kernel(const tq_cosmos_args a) {
+  __shared__ double s_w[4][TQ_MAX_NGSUM];
+  __shared__ int s_last;
+  if (threadIdx.x < 64) {
+    const int ticket = tq_group_reduce_rows(a, (int)blockIdx.x);
+    if (threadIdx.x == 0) s_last = ticket == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  tq_groups_sums_body<false>(a, s_w);
+}
+
 
 // AOI-sharded full-batch steps: rows -> per-AOI sites and gsum (what the all-reduce needs), nothing of the global
 // sites.  One wave per (AOI, channel) adds the rows that overlap the AOI (a single workgroup would walk 400 AOIs x 17 rows
@@ -1223,6 +1251,10 @@ static int check_args(const tq_cosmos_args* a, const char* who) {
     tq_set_error("tq_cosmos_*: Nt*F*C must be below 2^31 (unit indices are 32-bit on the device)");
     return TQ_ERR_ARG;
   }
+  if (a->images_by_slot && (a->crosstalk || !a->ndx)) {
+    tq_set_error("tq_cosmos_*: images_by_slot (a streamed window of AOIs) needs the AOI list ndx of the batch; cosmos model only");
+    return TQ_ERR_ARG;
+  }
   if (a->crosstalk && (a->C != 2 || a->K > 2)) {
     tq_set_error("tq_cosmos_*: the crosstalk model is implemented for Q = C = 2 and K <= 2");
     return TQ_ERR_ARG;
@@ -1290,6 +1322,7 @@ static tq_ksmogn_args cosmos_ksmogn_args(const tq_cosmos_args* a) {
   k.g_y = a->pix + (int64_t)(M + 2 + 3 * K) * B;
   k.nb = a->nb; k.fb = a->fb; k.C = a->C; k.F = a->F; k.P = a->P; k.K = K; k.O = a->O;
   k.scale = a->scale;
+  k.images_by_slot = a->images_by_slot;
   return k;
 }
 
@@ -1343,6 +1376,14 @@ static int launch_rows_sums(const tq_cosmos_args* a, hipStream_t st) {
   if (!a->sync || !a->aoi_part || !a->gsum) {
     tq_set_error("tq_cosmos_elbo_grads: the rows layout needs sync, aoi_part and gsum");
     return TQ_ERR_ARG;
+  }
+  static const bool groups = [] {
+    const char* e = getenv("TAPQIR_AMD_GROUPS");
+    return !(e && e[0] == '0');
+  }();
+  if (groups) {
+    hipLaunchKernelGGL(tq_group_sums_kernel, dim3((unsigned)tq_grp_count(tq_batch_units(*a))), dim3(256), 0, st, *a);
+    return check_launch("tq_group_sums_kernel");
   }
   hipLaunchKernelGGL(tq_rows_sums_kernel, dim3((unsigned)((a->nb * a->C + 3) / 4)), dim3(256), 0, st, *a);
   return check_launch("tq_rows_sums_kernel");

@@ -308,9 +308,9 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   // (B < 2^31 is checked on the host; 32-bit arithmetic, and no division at all for a contiguous batch)
   const uint32_t iu = (uint32_t)i;
   int n;
-  int64_t u;
+  int64_t u, u_img;  // dataset unit; unit whose tile `images` holds at that position (differs for a streamed window)
   if (a.ndx == nullptr && a.fdx == nullptr) {
-    u = i;
+    u = u_img = i;
     n = (int)(iu / (uint32_t)(a.F * a.C));
   } else {
     const uint32_t c = iu % (uint32_t)a.C, ab = iu / (uint32_t)a.C;
@@ -318,10 +318,11 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
     n = a.ndx ? a.ndx[ai] : (int)ai;
     const int f = a.fdx ? a.fdx[bi] : (int)bi;
     u = ((int64_t)n * a.F + f) * a.C + c;
+    u_img = a.images_by_slot ? ((int64_t)ai * a.F + f) * a.C + c : u;
   }
 
   // ---- stage the P x P tile: all loads of a unit in flight at once, 16 B per lane when aligned ----
-  const float* tile = a.images + u * npix;
+  const float* tile = a.images + u_img * npix;
   if ((npix & 3) == 0) {
     const float4* t4 = reinterpret_cast<const float4*>(tile);
     const int n4 = npix >> 2;

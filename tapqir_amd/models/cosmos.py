@@ -64,7 +64,8 @@ def initial_values(eng, data, collective=None):
     K, Nt, F, C = eng.K, eng.Nt, eng.F, eng.C
     Q = C
     f = lambda shape, v: torch.full(shape, float(v), dtype=torch.float64)
-    med = data_median(eng.images, collective)
+    # (a streamed data set keeps its images in host memory: the same counting median there)
+    med = data_median(eng.images if eng.images is not None else eng.images_host, collective)
     # (the reference takes median - offset.mean as it is; a non-positive value has no `positive` pre-image there)
     bg = (med - data.offset.mean).clamp(min=1e-3)
     return {
@@ -182,7 +183,7 @@ class cosmos(Model):
     def step_async(self) -> None:
         """One SVI update, nothing read back (the -ELBO stays on the device)."""
         eng = self.engine
-        if self.n is None and self.f is None and eng.device.type == "cuda" and hasattr(eng, "draw_subsample"):
+        if self.n is None and self.f is None and eng.device.type == "cuda" and hasattr(eng, "draw_subsample") and not eng.streamed:
             # the same two randperm draws as _subsample, made straight into the engine's pinned staging ring
             d = self.data
             ndx, fdx = eng.draw_subsample(self.nbatch_size or d.Nt, self.fbatch_size or d.F, self._subsample_gen)

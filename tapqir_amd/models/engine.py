@@ -45,7 +45,12 @@ class CosmosEngine:
     lazy_adam_default = True   # tq_cosmos_adam_catchup
 
     def __init__(self, data, K=2, priors=None, device="cuda", eps=None, seed=0, n_offset=0, Nt_global=None,
-                 crosstalk=False):
+                 crosstalk=False, hbm_budget=None):
+        """``hbm_budget`` (bytes; default: the TAPQIR_AMD_HBM_BUDGET environment variable, else unlimited): device memory the
+        IMAGES may take.  A data set whose resident form (the images and their interleaved copy) is larger is STREAMED: the
+        images stay in page-locked host memory and every step brings the AOIs it needs through two device windows, group by
+        group (the reference fetches every minibatch from host memory, tapqir/utils/dataset.py:140-151); parameters, optimiser
+        state and the 12 B per unit of data statistics stay resident (section "streamed data sets" of DESIGN.md)."""
         self.device = torch.device(device)
         self.lib = self._open_library()
         lib = self.lib
@@ -69,7 +74,16 @@ class CosmosEngine:
         self.n_offset = int(n_offset)
         dev = self.device
         f32 = torch.float32
-        self.images = data.images.to(dev, f32).contiguous()
+        if hbm_budget is None and os.environ.get("TAPQIR_AMD_HBM_BUDGET"):
+            hbm_budget = int(float(os.environ["TAPQIR_AMD_HBM_BUDGET"]))
+        img_bytes = 4 * data.images.numel()
+        self.streamed = bool(hbm_budget) and 2 * img_bytes > hbm_budget and self.device.type == "cuda"
+        if self.streamed:
+            if self.crosstalk:
+                raise ValueError("streaming of data sets larger than the device memory is implemented for the cosmos model")
+            self._init_windows(data, int(hbm_budget))
+        else:
+            self.images = data.images.to(dev, f32).contiguous()
         self.xy = data.xy.to(dev, f32).contiguous()
         self.is_ontarget = data.is_ontarget.to(dev, torch.uint8).contiguous()
         self.mask = data.mask.to(dev, torch.uint8).contiguous()
@@ -77,7 +91,7 @@ class CosmosEngine:
         self._mask_arg = self.mask if not bool(data.mask.all()) else None
         # tile-interleaved copy for the contiguous-batch pixel kernel (include/tapqir_hip.h); built by the
         # library so that any C caller gets the same layout
-        self.images_il = self._interleaved_images()
+        self.images_il = None if self.streamed else self._interleaved_images()
         off_s, off_l = merge_offsets(data.offset.samples, data.offset.weights)
         self.offset_samples, self.offset_logits = off_s.to(dev), off_l.to(dev)
         self.O = int(off_s.numel())
@@ -86,7 +100,10 @@ class CosmosEngine:
         if self.O == 1:
             U = self.Nt * self.F * self.C
             self.pixstats = torch.empty(3 * U, dtype=f32, device=dev)
-            self._image_stats(U)
+            if self.streamed:
+                self._image_stats_streamed()
+            else:
+                self._image_stats(U)
         self.layout = ParamLayout(self.Nt, self.F, self.C, self.K, self.P, self.eps, crosstalk=self.layout_crosstalk)
         n = self.layout.total
         self._params = torch.zeros(n, dtype=f32, device=dev)
@@ -176,18 +193,153 @@ class CosmosEngine:
         b = cp["b_loc"].detach().to(f32).reshape(U).contiguous()
         snr = torch.empty(self.K, U, dtype=f32, device=self.device)
         chi2 = torch.empty(U, dtype=f32, device=self.device)
-        a = _lib.SnrArgs()
+        gain = float(cp["gain_loc"])
         p = _lib.ptr
-        a.images, a.xy = p(self.images), p(self.xy)
-        a.height, a.width, a.x, a.y, a.background = p(h), p(w), p(x), p(y), p(b)
-        a.snr, a.chi2 = p(snr), p(chi2)
-        a.U, a.P, a.K = U, self.P, self.K
-        a.gain, a.offset_mean, a.offset_var = float(cp["gain_loc"]), float(offset_mean), float(offset_var)
-        self._run_snr_chi2(a)
+
+        def launch(images, xy, hh, ww, xx, yy, bb, snr_o, chi2_o, n_units):
+            a = _lib.SnrArgs()
+            a.images, a.xy = p(images), p(xy)
+            a.height, a.width, a.x, a.y, a.background = p(hh), p(ww), p(xx), p(yy), p(bb)
+            a.snr, a.chi2 = p(snr_o), p(chi2_o)
+            a.U, a.P, a.K = n_units, self.P, self.K
+            a.gain, a.offset_mean, a.offset_var = gain, float(offset_mean), float(offset_var)
+            self._run_snr_chi2(a)
+
+        if not self.streamed:
+            launch(self.images, self.xy, h, w, x, y, b, snr, chi2, U)
+        else:  # window by window (whole AOIs): the same kernel on slices of every array
+            fc = self.F * self.C
+            xy2 = self.xy.reshape(U, 2)
+            for aois in self._groups(None):
+                wi, n0, n = self._upload_group(aois), int(aois[0]), aois.numel()
+                torch.cuda.current_stream(self.device).wait_event(self._win_ready[wi])
+                u0, u1 = n0 * fc, (n0 + n) * fc
+                parts = [t[:, u0:u1].contiguous() for t in (h, w, x, y)]
+                snr_g = torch.empty(self.K, u1 - u0, dtype=f32, device=self.device)
+                chi2_g = torch.empty(u1 - u0, dtype=f32, device=self.device)
+                launch(self._win[wi], xy2[u0:u1].contiguous(), *parts, b[u0:u1].contiguous(), snr_g, chi2_g, u1 - u0)
+                snr[:, u0:u1] = snr_g
+                chi2[u0:u1] = chi2_g
+                ev = torch.cuda.Event()
+                ev.record()
+                self._win_free[wi] = ev
         return snr.view(self.K, self.Nt, self.F, self.C), chi2.view(self.Nt, self.F, self.C)
 
     def run_probs(self, a):
         _lib.check(self.lib.tq_cosmos_probs(C.byref(a), self._stream()), "tq_cosmos_probs")
+
+    # -- streamed data sets (images larger than the device memory they may take) --------------------------
+    def _init_windows(self, data, budget):
+        """Images in page-locked host memory; two device windows of W whole AOIs each (all frames of an AOI travel together:
+        the per-AOI sites need every frame of the batch, and an AOI's F C P P floats are contiguous on the host)."""
+        f32 = torch.float32
+        self.images = None
+        self.images_host = data.images.to("cpu", f32).contiguous().pin_memory()
+        Nt = self.images_host.shape[0]
+        per_aoi = 4 * self.images_host[0].numel()
+        self.window_aois = int(max(1, min(Nt, budget // (2 * per_aoi))))
+        shape = (self.window_aois,) + tuple(self.images_host.shape[1:])
+        self._win = [torch.empty(shape, dtype=f32, device=self.device) for _ in range(2)]
+        self._win_free = [None, None]  # event after the last launch that reads the window
+        self._win_ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self._copy_stream = torch.cuda.Stream(self.device)
+        self._win_count = 0
+
+    def _upload_group(self, aois):
+        """Bring the AOIs `aois` (host int64 tensor, in batch order) into the next window on the copy stream; returns the
+        window index.  Runs of consecutive AOIs are one copy."""
+        w = self._win_count % 2
+        self._win_count += 1
+        win = self._win[w]
+        with torch.cuda.stream(self._copy_stream):
+            if self._win_free[w] is not None:
+                self._copy_stream.wait_event(self._win_free[w])  # the kernels that read this window two groups ago are done
+            idx = aois.tolist()
+            j = 0
+            while j < len(idx):
+                k = j
+                while k + 1 < len(idx) and idx[k + 1] == idx[k] + 1:
+                    k += 1
+                win[j:k + 1].copy_(self.images_host[idx[j]:idx[k] + 1], non_blocking=True)
+                j = k + 1
+            self._win_ready[w].record(self._copy_stream)
+        return w
+
+    def _groups(self, ndx):
+        aois = torch.arange(self.Nt) if ndx is None else ndx.detach().to("cpu", torch.int64).reshape(-1)
+        return [aois[i:i + self.window_aois] for i in range(0, aois.numel(), self.window_aois)]
+
+    def _image_stats_streamed(self):
+        U, fc = self.Nt * self.F * self.C, self.F * self.C
+        groups = self._groups(None)
+        nxt = self._upload_group(groups[0])
+        for g, aois in enumerate(groups):
+            w, n0, n = nxt, int(aois[0]), aois.numel()
+            torch.cuda.current_stream(self.device).wait_event(self._win_ready[w])
+            if g + 1 < len(groups):
+                nxt = self._upload_group(groups[g + 1])
+            tmp = torch.empty(3, n * fc, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.tq_image_stats(_lib.ptr(self._win[w]), _lib.ptr(self.offset_samples), _lib.ptr(tmp), n * fc, self.P,
+                                               self._stream()), "tq_image_stats")
+            self.pixstats.view(3, U)[:, n0 * fc:(n0 + n) * fc] = tmp
+            ev = torch.cuda.Event()
+            ev.record()
+            self._win_free[w] = ev
+
+    def _step_streamed(self, ndx, fdx):
+        """One SVI step of a streamed data set: the step's AOIs in groups of at most `window_aois`; per group the staged
+        launches of a gathered batch (lazy-Adam catch-up for minibatches, local sampling, likelihood + per-unit + per-AOI
+        terms with the Adam of the local parameters fused in) on the window the copy stream has filled meanwhile; the
+        cross-unit sums of the groups are added and ONE tail (global sites, ELBO, Adam of the per-AOI / global parameters)
+        closes the step.  Draws are keyed by the global unit index, so the step is the resident step up to the order in
+        which the groups' sums are added."""
+        self._finish_pending()
+        self._finish_tail()
+        groups = self._groups(ndx)
+        nb_total = sum(g.numel() for g in groups)
+        fb = self.F if fdx is None else int(fdx.numel())
+        minibatch = nb_total < self.Nt or fb < self.F
+        lazy = minibatch and self.lazy_adam
+        self._workspace(min(self.window_aois, nb_total), fb)  # (a new workspace joins first: before the lazy clock is started)
+        ws_key = self._ws_key
+        if lazy:
+            if not self._stale:
+                self._last_step.fill_(self.adam_step)
+                self._stale = True
+        else:
+            self._catch_up_all()
+        fdx_dev = None if fdx is None else self._index_to_device(fdx, 1)
+        gtot = torch.zeros_like(self.gsum)
+        cur = torch.cuda.current_stream(self.device)
+        nxt = self._upload_group(groups[0])
+        a = None
+        for g, aois in enumerate(groups):
+            w = nxt
+            nd = aois.to(self.device, torch.int32)
+            a = self.make_args(nd, fdx_dev, draw_globals=True, _for_step=True, _ws=ws_key)
+            a.images, a.images_il, a.images_by_slot = _lib.ptr(self._win[w]), None, 1
+            a.scale_n = self.Nt_global / self._nb_global(nb_total)
+            a.scale = a.scale_n * self.F / fb
+            a.zero_grad = int(minibatch)
+            a.fuse_adam = int(not minibatch or lazy)
+            if not lazy:
+                a.last_step = None
+            if g == 0:
+                self.call("cosmos_sample_globals", a)
+            cur.wait_event(self._win_ready[w])
+            if g + 1 < len(groups):
+                nxt = self._upload_group(groups[g + 1])  # travels while this group computes
+            if lazy:
+                self._adam_catchup(a, 0)
+            self.call("cosmos_sample_locals", a)
+            self.call("cosmos_elbo_grads", a)
+            gtot += self.gsum
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._win_free[w] = ev
+        self.gsum.copy_(gtot)
+        self._tail_reduced(a, None)
+        self.adam_step += 1
 
     # -- parameter / moment buffers ---------------------------------------------------------------
     # Reading them from outside the step completes deferred work first: the pending tail of a pipelined step and the
@@ -327,14 +479,15 @@ class CosmosEngine:
         return (dev[:nb] if take_n else None), (dev[Nt:Nt + fb] if take_f else None)
 
     def make_args(self, ndx=None, fdx=None, draw_globals=True, global_weight=1.0, step=None, draw_locals=None,
-                  _for_step=False):
+                  _for_step=False, _ws=None):
         if not _for_step:
             # staged calls from outside read the parameters of arbitrary units and overwrite globals / gsum / grad: finish
             # a pipelined tail or an in-flight all-reduce first, then bring every unit to the current Adam step
             self.join()
         nb = self.Nt if ndx is None else int(ndx.numel())
         fb = self.F if fdx is None else int(fdx.numel())
-        self._workspace(nb, fb)
+        if _ws is None:
+            self._workspace(nb, fb)  # (_ws: the caller has set up a workspace for batches up to that size)
         ndx, fdx = self._indices_to_device(ndx, fdx)
         # keep the index tensors alive while kernels run (the previous step's too: its tail may still be pending)
         self._keep_prev, self._keep = getattr(self, "_keep", None), (ndx, fdx)
@@ -513,6 +666,11 @@ class CosmosEngine:
         sites, Adam of the per-AOI and global parameters) is deferred: it runs after the NEXT step's local guide
         sampling, which needs local parameters only, so the collective's latency hides behind that kernel.  ``join()``
         (called by every read-out) completes a deferred tail."""
+        if self.streamed:
+            if allreduce is not None:
+                raise NotImplementedError("AOI sharding of a streamed data set: shard first, each rank then streams its own AOIs "
+                                          "(not built: a rank's shard of every BASELINE config fits its 288 GB many times over)")
+            return self._step_streamed(ndx, fdx)
         if self.pixel_mode is None and ndx is None and fdx is None and self.pipelined_tail:
             self.autotune_pixel()
         if self.fuse_unit is None and ndx is None and fdx is None and allreduce is None and self.pipelined_tail:
@@ -560,7 +718,14 @@ class CosmosEngine:
             if pending is not None and not a.fuse_adam:
                 self._finish_pending()  # a minibatch step samples after the dense Adam of the previous one
                 pending = None
-            if pending is not None and self.split_sampling:
+            if pending is not None and self.split_sampling and getattr(pending[1], "in_stream", False):
+                # the collective was issued on this stream (tapqir_amd.rccl.RcclDirect): stream order is the dependency.  ONE
+                # sampling launch that carries the pending step's post-all-reduce tail and this step's global draws
+                prev, _ = self._pending
+                self._pending = None
+                _lib.check(self.lib.tq_cosmos_sample_locals_range(C.byref(a), 0, 1 + 4 * self.K, C.byref(prev), self._stream()),
+                           "tq_cosmos_sample_locals_range")
+            elif pending is not None and self.split_sampling:
                 # first half of the local sites while the all-reduce is in flight; the rest in a launch that also
                 # carries the pending step's post-all-reduce tail and this step's global draws
                 nsites = 1 + 4 * self.K

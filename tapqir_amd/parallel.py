@@ -75,11 +75,24 @@ class Collective:
         return int(t[0])
 
 
-def make_allreduce(group=None, async_op=False):
-    """The single collective of a step: in-place sum of the cross-unit sums over all ranks.  With ``async_op`` the
-    collective is left in flight and its handle returned: CosmosEngine.step then overlaps it with the next step's
-    local guide sampling (full-batch steps)."""
+def make_allreduce(group=None, async_op=False, direct=None):
+    """The single collective of a step: in-place sum of the cross-unit sums over all ranks.
+
+    ``direct`` (default: on when the process group's backend is "nccl", off with TAPQIR_AMD_RCCL_DIRECT=0): the all-reduce is
+    ``ncclAllReduce`` of RCCL issued on the launch stream itself (``tapqir_amd.rccl.RcclDirect``): no second stream, no event
+    hand-overs; the tail of the step then rides in the next step's sampling launch in stream order.  Otherwise
+    ``torch.distributed.all_reduce``; with ``async_op`` the collective is left in flight and its handle returned:
+    CosmosEngine.step then overlaps it with the next step's local guide sampling (full-batch steps)."""
+    import os
+
     import torch.distributed as dist
+
+    if direct is None:
+        direct = dist.get_backend(group) == "nccl" and os.environ.get("TAPQIR_AMD_RCCL_DIRECT", "1") != "0"
+    if direct:
+        from tapqir_amd.rccl import RcclDirect
+
+        return RcclDirect(group)
 
     def allreduce(gsum: torch.Tensor):
         return dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group, async_op=async_op) if async_op else \

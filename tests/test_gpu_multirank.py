@@ -3,7 +3,10 @@ AOI-sharded data parallelism on the GPU: two rank processes drive the HIP librar
 build) through the sharded launch sequence -- sampling split around the in-flight all-reduce, tq_cosmos_tail_reduced
 carried by the next step's sampling launch -- and must reproduce the single-process fit.
 
-  * backend "nccl" (= RCCL): one GPU per rank; skipped on a box with fewer than two GPUs;
+  * backend "nccl" (= RCCL): one GPU per rank; skipped on a box with fewer than two GPUs.  The step's all-reduce is then
+    ``ncclAllReduce`` issued on the launch stream (tapqir_amd/rccl.py) -- that path also runs with ONE rank on a one-GPU box
+    (test_rccl_direct_single_rank: communicator from a broadcast unique id, collective in stream order, the tail of a step
+    inside the next step's sampling launch);
   * backend "gloo": both ranks share cuda:0 and the 48-byte all-reduce is staged through the host -- the same kernels,
     launch order and stream semantics, runnable on a one-GPU box.
 """
@@ -58,7 +61,7 @@ def _worker(rank, world, port, q, backend, minibatch):
     eng.join()
     torch.cuda.synchronize()
     out = {"rank": rank, "lo": lo, "hi": hi, "elbo": float(eng.elbo_out[0]), "pending": pending,
-           "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+           "ranks": dist.get_world_size(), "backend": dist.get_backend(), "allreduce": getattr(allreduce, "backend", "torch"),
            "params": {n: v.detach().cpu().clone().numpy() for n, v in eng.named("params").items()}}
     if rank == 0:
         per = N // world
@@ -102,3 +105,23 @@ def test_two_gpu_ranks_equal_single_process(backend, minibatch):
             fp = ref["full_params"][n]
             want = fp[:, lo:hi] if v.ndim == 4 else (fp[lo:hi] if v.ndim == 3 else fp)
             assert abs(v - want).max() <= 5e-6, n
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("minibatch", [False, True], ids=["full_batch_in_stream", "minibatch_lazy_adam"])
+def test_rccl_direct_single_rank(minibatch):
+    """One rank, backend "nccl": the sharded launch sequence with the all-reduce issued by RCCL on the launch stream."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + 17 * int(minibatch)) % 2000
+    p = ctx.Process(target=_worker, args=(0, 1, port, q, "nccl", minibatch))
+    p.start()
+    o = q.get(timeout=480)
+    p.join(60)
+    assert p.exitcode == 0
+    assert o["ranks"] == 1 and o["backend"] == "nccl" and o["allreduce"] == "rccl-direct"
+    if not minibatch:
+        assert o["pending"]
+    assert abs(o["elbo"] - o["full_elbo"]) <= 2e-6 * abs(o["full_elbo"])
+    for n, v in o["params"].items():
+        assert abs(v - o["full_params"][n]).max() <= 5e-6, n
