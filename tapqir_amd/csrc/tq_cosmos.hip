@@ -1621,7 +1621,7 @@ extern "C" int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos
   const bool one = a->O == 1 && a->pixstats;
   // one workgroup per 16 units + the one that runs the tail and the global draws
   const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) + 1), block(256);
-  const size_t lds = sizeof(float) * tq_tile16_lds_floats(a->P, a->K);
+  const size_t lds = sizeof(float) * tq_tile16_lds_floats(a->P, a->K, a->O);
   const int code = prev ? tq_prev_code(*prev) : 0;
   const tq_cosmos_args& pv = prev ? *prev : *a;
   hipStream_t st = (hipStream_t)stream;

@@ -788,7 +788,7 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
     return TQ_ERR_ARG;
   }
   const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK)), block(TQ_BLOCK);
-  const size_t lds = sizeof(float) * tq_tile16_lds_floats(a.P, K);
+  const size_t lds = sizeof(float) * tq_tile16_lds_floats(a.P, K, a.O);
   if (bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, ONE, true>), grid, block, lds, st, a, B);
   else hipLaunchKernelGGL((tq_ksmogn_kernel<K, ONE, false>), grid, block, lds, st, a, B);
   return launch_status("tq_ksmogn_kernel");

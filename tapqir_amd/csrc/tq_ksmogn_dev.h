@@ -89,7 +89,7 @@ __device__ __forceinline__ void tq_pixel_one_offset(TqPixAcc<K>& A, float v, flo
 template <int K, bool BWD, bool FAST>
 __device__ __forceinline__ void tq_pixel_multi_offset(TqPixAcc<K>& A, const tq_ksmogn_args& a, const TqOffsetInfo& h,
                                                       float D, float ln_g, float b, const float* spot, const float* W,
-                                                      float fic, float fj, float g, float rg) {
+                                                      float fic, float fj, float g, float rg, const float* tab = nullptr) {
   constexpr int M = 1 << K;
   float mu[M], lp[M], da[M], gq[M];
 #pragma unroll
@@ -99,7 +99,8 @@ __device__ __forceinline__ void tq_pixel_multi_offset(TqPixAcc<K>& A, const tq_k
     for (int k = 0; k < K; ++k)
       if ((mi >> k) & 1) mu[mi] += spot[k];
   }
-  tq_pix_multi_offset<M, BWD, FAST>(D, mu, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, lp, da, gq);
+  if (tab) tq_pix_multi_offset_tab<M, BWD, FAST>(D, mu, tab, a.O, h, g, rg, ln_g, lp, da, gq);
+  else tq_pix_multi_offset<M, BWD, FAST>(D, mu, a.offset_samples, a.offset_logits, a.O, h, g, rg, ln_g, lp, da, gq);
   float q[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) q[k] = 0.0f;
@@ -258,12 +259,19 @@ template <int K, bool ONE_OFFSET, bool BWD, bool FAST>
 __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_args& a,
                                               const float* __restrict__ s_tile, const float* __restrict__ s_fac,
                                               int r, int P, int npix, float b, const float* amph, float g, float rg,
-                                              float ln_g, const float* W) {
+                                              float ln_g, const float* W, const float* __restrict__ s_off = nullptr) {
+  // s_off (offset histograms): [4] TqOffsetInfo, then the per-offset table of tq_pix_multi_offset_tab, in LDS
   const uint32_t magic = (1u << 20) / (uint32_t)P + 1u;  // exact pix / P for pix < 4096, P <= 64
   const float off0 = a.offset_samples[0];
   const float c0 = 0.5f * (float)(P - 1);
   TqOffsetInfo h;
-  if (!ONE_OFFSET) tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
+  if (!ONE_OFFSET) {
+    if (s_off) {
+      h.dmin = s_off[0]; h.dmax = s_off[1]; h.lw2max = s_off[2]; h.lw2min = s_off[3];
+    } else {
+      tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
+    }
+  }
   for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
     const int j = (int)(((uint32_t)pix * magic) >> 20);
     const int ic = pix - j * P;
@@ -275,7 +283,7 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
 #pragma unroll
     for (int k = 0; k < K; ++k) spot[k] = amph[k] * s_fac[(2 * k) * TQ_MAX_P + ic] * s_fac[(2 * k + 1) * TQ_MAX_P + j];
     if (ONE_OFFSET) tq_pixel_one_offset<K, BWD, FAST>(A, D - off0, b, spot, W, fic, fj, g, rg, ln_g);
-    else tq_pixel_multi_offset<K, BWD, FAST>(A, a, h, D, ln_g, b, spot, W, fic, fj, g, rg);
+    else tq_pixel_multi_offset<K, BWD, FAST>(A, a, h, D, ln_g, b, spot, W, fic, fj, g, rg, s_off ? s_off + 4 : nullptr);
   }
 }
 
@@ -285,8 +293,9 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
 // The 16 units [blk * 16, blk * 16 + 16) of the batch by one workgroup of 256 threads; `smem` holds
 // tq_tile16_lds_floats(P, K) floats.  Called by tq_ksmogn_kernel (tq_ksmogn.hip) and by the single-launch minibatch step
 // (tq_cosmos.hip), which runs it between its sampling and per-unit phases.
-__host__ __device__ inline size_t tq_tile16_lds_floats(int P, int K) {
-  return (size_t)TQ_UNITS_PER_BLOCK * (tq_tile_stride(P * P) + 2 * K * TQ_MAX_P);
+#define TQ_OFFTAB_MAX 2048  /* offsets whose table the workgroup keeps in LDS (28 KB); longer histograms read global memory */
+__host__ __device__ inline size_t tq_tile16_lds_floats(int P, int K, int O = 1) {
+  return (size_t)TQ_UNITS_PER_BLOCK * (tq_tile_stride(P * P) + 2 * K * TQ_MAX_P) + ((O > 1 && O <= TQ_OFFTAB_MAX) ? 4 + 3 * (size_t)O : 0);
 }
 template <int K, bool ONE_OFFSET, bool BWD>
 __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const int64_t B, const int64_t blk, float* smem) {
@@ -358,6 +367,37 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   float W[M];
   if (BWD) tq_load_weights<K>(a, B, i, u, n, W);
 
+  // offset histogram: extrema and per-offset constants once per workgroup (every thread of the workgroup is here)
+  float* s_off = nullptr;
+  if (!ONE_OFFSET && a.O <= TQ_OFFTAB_MAX) {
+    s_off = smem + TQ_UNITS_PER_BLOCK * (stride + 2 * K * TQ_MAX_P);
+    if (tid < 64) {  // min / max are exact: the values of tq_offset_info
+      float lo = INFINITY, hi = -INFINITY, lw = -INFINITY, lwn = INFINITY;
+      for (int o = tid; o < a.O; o += 64) {
+        const float sv = a.offset_samples[o], lv = a.offset_logits[o];
+        lo = fminf(lo, sv); hi = fmaxf(hi, sv); lw = fmaxf(lw, lv); lwn = fminf(lwn, lv);
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64));
+        lw = fmaxf(lw, __shfl_xor(lw, d, 64)); lwn = fminf(lwn, __shfl_xor(lwn, d, 64));
+      }
+      if (tid == 0) {
+        s_off[0] = lo; s_off[1] = hi; s_off[2] = lw * TQ_LOG2E; s_off[3] = lwn * TQ_LOG2E;
+      }
+    }
+    __syncthreads();
+    const float dmin = s_off[0], lw2max = s_off[2], beta2 = rg * TQ_LOG2E;
+    for (int o = tid; o < a.O; o += TQ_BLOCK) {  // the expressions of tq_pix_multi_offset
+      const float sv = a.offset_samples[o];
+      const float dd = sv - dmin;
+      s_off[4 + 3 * o] = sv;
+      s_off[4 + 3 * o + 1] = dd;
+      s_off[4 + 3 * o + 2] = (a.offset_logits[o] * TQ_LOG2E - lw2max) + beta2 * dd;
+    }
+    __syncthreads();
+  }
+
   // the tile and the factor table of a unit are written and read by the same 16 lanes of ONE wave:
   // LDS operations of a wave complete in order, so no workgroup barrier is needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -369,8 +409,8 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   tq_acc_zero<K>(A);
   // alpha(m) >= background / gain for every combination and pixel: one wave-uniform test picks
   // the branch-free loop (one-term Binet correction valid) or the general one
-  if (__all(b * rg >= TQ_FAST_ALPHA)) tq_pixel_loop<K, ONE_OFFSET, BWD, true>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W);
-  else tq_pixel_loop<K, ONE_OFFSET, BWD, false>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W);
+  if (__all(b * rg >= TQ_FAST_ALPHA)) tq_pixel_loop<K, ONE_OFFSET, BWD, true>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, s_off);
+  else tq_pixel_loop<K, ONE_OFFSET, BWD, false>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, s_off);
 
   // ---- reduce over the unit's 16 lanes, assemble and store ------------------------------------------
 #pragma unroll

@@ -180,6 +180,58 @@ TQ_HD void tq_pix_multi_offset(float D, const float* mu, const float* samples, c
   for (int mi = 0; mi < M; ++mi) tq_mo_finish(FAST, mu[mi], vs[mi], vhi, S0[mi], S1[mi], S2[mi], h, g, rg, ln_g, &lp[mi], &da[mi], &gq[mi]);
 }
 
+// The same with the per-offset constants taken from a table tab[3 o] = {delta_o, delta_o - delta_min, log2 w_o - log2 w_max +
+// beta (delta_o - delta_min) log2 e} (the expressions of the loop above, formed once per workgroup: the 16-lane kernel keeps
+// the table in LDS -- as two scalar loads from global memory per offset and pixel, the offset loop of a minibatch step
+// with a 50-value histogram spent most of its time waiting for them).
+template <int M, bool BWD, bool FAST>
+TQ_HD void tq_pix_multi_offset_tab(float D, const float* mu, const float* tab, int O, const TqOffsetInfo& h, float g, float rg,
+                                   float ln_g, float* lp, float* da, float* gq) {
+  const float vhi = D - h.dmin;
+  if (!(vhi > 0.0f)) {  // every offset at or above the pixel (ksmogn.py:226): log 0, no gradient
+    for (int mi = 0; mi < M; ++mi) {
+      lp[mi] = -INFINITY;
+      da[mi] = 0.0f;
+      gq[mi] = 0.0f;
+    }
+    return;
+  }
+  float vlo = D - h.dmax;
+  if (!(vlo > 0.0f)) {  // some offsets are masked: the smallest valid v
+    vlo = vhi;
+    for (int o = 0; o < O; ++o) {
+      const float v = D - tab[3 * o];
+      if (v > 0.0f) vlo = fminf(vlo, v);
+    }
+  }
+  const float rvhi = TQ_FRCP(vhi);
+  float a[M], c[M], vs[M], S0[M], S1[M], S2[M];
+  for (int mi = 0; mi < M; ++mi) {
+    vs[mi] = tq_mo_reference(mu[mi], g, rg, vlo, vhi, rvhi, &a[mi], &c[mi]);
+    S0[mi] = S1[mi] = S2[mi] = 0.0f;
+  }
+  // branch-free: an offset at or above the pixel contributes t = 0 (its logarithm is taken of a clamped argument and
+  // selected away), so that the loads and transcendentals of consecutive offsets overlap
+#pragma unroll 4
+  for (int o = 0; o < O; ++o) {
+    const float v = D - tab[3 * o];
+    const bool on = v > 0.0f;
+    const float dl = TQ_FLOG2((on ? v : vhi) * rvhi);
+    const float dd = tab[3 * o + 1];
+    const float db = tab[3 * o + 2];
+    for (int mi = 0; mi < M; ++mi) {
+      const float e = TQ_FEXP2((a[mi] * dl + c[mi]) + db);
+      const float t = on ? e : 0.0f;
+      S0[mi] += t;
+      if (BWD) {
+        S1[mi] += t * dl;
+        S2[mi] += t * dd;
+      }
+    }
+  }
+  for (int mi = 0; mi < M; ++mi) tq_mo_finish(FAST, mu[mi], vs[mi], vhi, S0[mi], S1[mi], S2[mi], h, g, rg, ln_g, &lp[mi], &da[mi], &gq[mi]);
+}
+
 // One pixel, every combination, ONE offset (no data statistics needed: used by the crosstalk kernel, whose
 // combinations all carry spots in every channel).  Same Binet form as above with S0 = 1:
 //   log p = [ln w - ln sqrt(2 pi) - ln v] + alpha phi(v / mu) + (1/2) ln alpha - S(alpha).
