@@ -266,7 +266,14 @@ typedef struct {
                                   same `sync` words (a launch counter of the host) */
   int32_t images_by_slot;      /* 1: `images` is a window holding the AOIs of this batch in batch order (tq_ksmogn_args.images_by_slot):
                                   data sets larger than the device memory, whose AOIs the host streams in group by group */
+  int32_t* next_ndx;           /* tq_cosmos_minibatch_step: [nb] or NULL, and */
+  int32_t* next_fdx;           /* [fb] or NULL -- the launch also draws the NEXT step's subsample, `randperm(Nt)[:nb]` /
+                                  `randperm(F)[:fb]` of pyro.plate (cosmos.py:194-208), as the nb / fb smallest of Nt / F Philox
+                                  keys (stream: seed, step + 1) in its tail workgroup, after the flag is published: a host that
+                                  passes them as ndx / fdx of the next call never draws, stages or copies an index
+                                  (Nt, F <= TQ_SUBSAMPLE_MAX) */
 } tq_cosmos_args;
+#define TQ_SUBSAMPLE_MAX 2048
 
 #define TQ_TAIL_AUTO 0
 #define TQ_TAIL_ROWS16 1

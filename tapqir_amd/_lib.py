@@ -64,7 +64,7 @@ class CosmosArgs(C.Structure):
         ("seed", C.c_uint64), ("step", C.c_uint32),
         ("last_step", C.c_void_p), ("beta1_d", C.c_double), ("beta2_d", C.c_double),
         ("pixel_mode", C.c_int32), ("tail_kind", C.c_int32), ("sync", C.c_void_p), ("sync_value", C.c_int32),
-        ("images_by_slot", C.c_int32),
+        ("images_by_slot", C.c_int32), ("next_ndx", C.c_void_p), ("next_fdx", C.c_void_p),
     ]
 
 

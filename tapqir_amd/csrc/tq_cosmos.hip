@@ -1004,6 +1004,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
 // waiting workgroups cannot deadlock whatever the dispatch order.  The tail of THIS step runs in the next launch (or in
 // tq_cosmos_tail).
 // =============================================================================================================
+// The next step's subsample, drawn by the tail workgroup of a minibatch launch: `take` of `n` indices without replacement =
+// the indices of the `take` smallest of n Philox keys (stream: seed, step, site), by a bitonic sort of (key << 32 | index)
+// in LDS (256 threads, n <= TQ_SUBSAMPLE_MAX; `buf` holds 2 * pow2(n) uint32 words).  The law of randperm(n)[:take]
+// (pyro.plate's subsample, cosmos.py:194-208) up to the order of the selected indices, which no sum depends on.
+__device__ __forceinline__ void tq_draw_subsample(uint64_t* buf, uint64_t seed, uint32_t step, uint32_t site, int n, int take,
+                                                  int32_t* out) {
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int i = threadIdx.x; i < n2; i += 256) {
+    uint64_t key = ~0ull;
+    if (i < n) {
+      TqPhilox s;
+      tq_philox_init(&s, seed, step, site, (uint64_t)i);
+      key = ((uint64_t)tq_philox_next(&s) << 32) | (uint32_t)i;
+    }
+    buf[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (n2 >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const uint64_t x = buf[lo], y = buf[hi];
+        const bool up = (lo & k) == 0;
+        if ((x > y) == up) {
+          buf[lo] = y;
+          buf[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < take; t += 256) out[t] = (int32_t)(uint32_t)buf[t];
+}
+#define TQ_SITE_SUBSAMPLE_N 0xA00u
+#define TQ_SITE_SUBSAMPLE_F 0xA01u
+
 template <int K, bool ONE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void tq_minibatch_kernel(
     const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const tq_ksmogn_args k, const int64_t B) {
@@ -1070,6 +1107,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       __hip_atomic_store(&a.sync[1], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     TQ_TAIL_STAMP(11)
+    // the NEXT step's subsample (nobody waits for it: the next launch reads it)
+    if (a.next_ndx && a.nb < a.Nt) {
+      tq_draw_subsample((uint64_t*)smem, a.seed, a.step + 1, TQ_SITE_SUBSAMPLE_N, a.Nt, a.nb, a.next_ndx);
+      __syncthreads();
+    }
+    if (a.next_fdx && a.fb < a.F) tq_draw_subsample((uint64_t*)smem, a.seed, a.step + 1, TQ_SITE_SUBSAMPLE_F, a.F, a.fb, a.next_fdx);
     if (tid == 0) count_out();
     return;
   }
@@ -1621,7 +1664,15 @@ extern "C" int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos
   const bool one = a->O == 1 && a->pixstats;
   // one workgroup per 16 units + the one that runs the tail and the global draws
   const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) + 1), block(256);
-  const size_t lds = sizeof(float) * tq_tile16_lds_floats(a->P, a->K, a->O);
+  size_t lds = sizeof(float) * tq_tile16_lds_floats(a->P, a->K, a->O);
+  if (a->next_ndx || a->next_fdx) {
+    if ((a->next_ndx && a->Nt > TQ_SUBSAMPLE_MAX) || (a->next_fdx && a->F > TQ_SUBSAMPLE_MAX)) {
+      tq_set_error("tq_cosmos_minibatch_step: next_ndx / next_fdx need Nt, F <= TQ_SUBSAMPLE_MAX");
+      return TQ_ERR_ARG;
+    }
+    const size_t sort = 2 * sizeof(uint64_t) * TQ_SUBSAMPLE_MAX / 2;  // pow2(n) <= TQ_SUBSAMPLE_MAX keys of 8 bytes
+    if (lds < sort) lds = sort;
+  }
   const int code = prev ? tq_prev_code(*prev) : 0;
   const tq_cosmos_args& pv = prev ? *prev : *a;
   hipStream_t st = (hipStream_t)stream;

@@ -183,6 +183,13 @@ class cosmos(Model):
     def step_async(self) -> None:
         """One SVI update, nothing read back (the -ELBO stays on the device)."""
         eng = self.engine
+        d = self.data
+        if (self.n is None and self.f is None and self.allreduce is None and eng.device.type == "cuda"
+                and hasattr(eng, "step_subsampled")
+                and eng.step_subsampled(self.nbatch_size or d.Nt, self.fbatch_size or d.F, self._subsample_gen)):
+            # the subsample of this step was drawn on the device by the previous launch (CosmosEngine.step_subsampled)
+            self._probs = None
+            return
         if self.n is None and self.f is None and eng.device.type == "cuda" and hasattr(eng, "draw_subsample") and not eng.streamed:
             # the same two randperm draws as _subsample, made straight into the engine's pinned staging ring
             d = self.data

@@ -388,6 +388,8 @@ class CosmosEngine:
         # reload) must not leave a ticket counter that no later launch can start from
         self._sync.zero_()
         self._sync_value = 0
+        if "_sub" in self.__dict__:
+            self._sub["ready"] = None  # a device-drawn subsample belongs to the step count it was drawn for
 
     # -- workspace ---------------------------------------------------------------------------------
     def _workspace(self, nb, fb):
@@ -658,7 +660,34 @@ class CosmosEngine:
         self.step_times_ms = times
         return self.fuse_unit
 
-    def step(self, ndx=None, fdx=None, allreduce=None):
+    def step_subsampled(self, nb, fb, generator=None):
+        """A minibatch step on a subsample the DEVICE has drawn: the single-launch minibatch step also draws the next step's
+        `randperm(Nt)[:nb]`, `randperm(F)[:fb]` (include/tapqir_hip.h: next_ndx / next_fdx) into the other of two index
+        slots, so the host of a running fit neither draws, stages nor copies an index -- at the default 10 x 512 the two
+        host-side randperm calls and their copy, not the GPU, bounded ``Model.run``.  The first step of a sequence (and any
+        step whose batch sizes differ from what the previous launch prepared) takes a host draw from ``generator``.  Returns
+        False if this engine cannot run that path (the caller then passes its own subsample to ``step``)."""
+        nb, fb = min(int(nb), self.Nt), min(int(fb), self.F)
+        if not (self.fused_minibatch and self.lazy_adam and self.pipelined_tail and not self.crosstalk and not self.streamed
+                and (nb < self.Nt or fb < self.F) and fb * self.C >= 16 and max(self.Nt, self.F) <= 2048  # TQ_SUBSAMPLE_MAX
+                and os.environ.get("TAPQIR_AMD_DEVICE_SUBSAMPLE", "1") != "0"):
+            return False
+        st = self.__dict__.setdefault("_sub", {"slots": [torch.zeros(self.Nt + self.F, dtype=torch.int32, device=self.device)
+                                                          for _ in range(2)], "turn": 0, "ready": None})
+        cur, Nt = st["turn"], self.Nt
+        slot, nxt = st["slots"][cur], st["slots"][1 - cur]
+        if st["ready"] != (nb, fb, self.adam_step):
+            if nb < self.Nt:
+                slot[:nb].copy_(torch.randperm(self.Nt, generator=generator)[:nb].to(torch.int32))
+            if fb < self.F:
+                slot[Nt:Nt + fb].copy_(torch.randperm(self.F, generator=generator)[:fb].to(torch.int32))
+        ndx = slot[:nb] if nb < self.Nt else None
+        fdx = slot[Nt:Nt + fb] if fb < self.F else None
+        self.step(ndx, fdx, _next_sub=(nxt[:nb] if nb < self.Nt else None, nxt[Nt:Nt + fb] if fb < self.F else None))
+        st["turn"], st["ready"] = 1 - cur, (nb, fb, self.adam_step)
+        return True
+
+    def step(self, ndx=None, fdx=None, allreduce=None, _next_sub=None):
         """One SVI step; returns nothing (the ELBO stays on the device in ``elbo_out``).
 
         ``allreduce(gsum)`` sums the cross-unit sums over the ranks of an AOI-sharded run.  If it returns a handle with
@@ -698,6 +727,8 @@ class CosmosEngine:
                 prev = self._tail_args
                 self._sync_value = self._sync_value % 0x3FFFFFFF + 1  # never 0, never the same value twice in a row
                 a.sync_value = self._sync_value
+                if _next_sub is not None:
+                    a.next_ndx, a.next_fdx = _lib.ptr(_next_sub[0]), _lib.ptr(_next_sub[1])
                 _lib.check(self.lib.tq_cosmos_minibatch_step(C.byref(a), None if prev is None else C.byref(prev),
                                                               self._stream()), "tq_cosmos_minibatch_step")
                 a.tail_kind = 1  # TQ_TAIL_ROWS16
