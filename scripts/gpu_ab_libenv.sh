@@ -6,7 +6,7 @@ for round in 1 2 3; do
   for cfg in "$@"; do
     lib=${cfg%%:*}; envs=""
     [ "$cfg" != "$lib" ] && envs=$(echo ${cfg#*:} | tr ',' ' ')
-    env TAPQIR_AMD_SITE_ROWS=6 TAPQIR_AMD_LIB=$R/tapqir_amd/$lib $envs timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu --trained-steps ${TRAINED:-0} 2>/dev/null | python -c "
+    env TAPQIR_AMD_LIB=$R/tapqir_amd/$lib $envs timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu --trained-steps ${TRAINED:-0} 2>/dev/null | python -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 print('$cfg', 'step_ms=%.4f'%d['ms_per_step'], 'mb_ms=%.4f'%d['minibatch_10x512']['ms_per_step'], 'trained=%.4f'%d.get('trained_regime',{}).get('ms_per_step',float('nan')))"

@@ -220,10 +220,13 @@ __device__ __forceinline__ void tq_site_beta_compact(const tq_cosmos_args& a, co
 
 // one site of one unit per lane; workgroups are uniform in the site (grid.y), AffineBeta sites go through the compaction
 __device__ __forceinline__ void tq_sample_site_wg(const tq_cosmos_args& a, const int site, const int64_t i, const int64_t B) {
+#ifndef TQ_DIAG_NO_COMPACT  // (diagnostic builds: the plain per-lane evaluation everywhere)
   if (site > a.K) {
     __shared__ TqBetaCompactLds s_bc;
     tq_site_beta_compact(a, site, i, i < B, s_bc);
-  } else if (i < B) {
+  } else
+#endif
+  if (i < B) {
     tq_body_site(a, site, i);
   }
 }
