@@ -222,12 +222,25 @@ class Runner:
         if use_dist:
             import torch.distributed as dist
 
+            direct = None
             if os.environ.get("TAPQIR_AMD_RCCL_DIRECT", "1") != "0":
-                # ncclAllReduce of RCCL on the launch stream itself (tapqir_amd/rccl.py): stream order is the only dependency
+                # ncclAllReduce of RCCL on the launch stream itself (tapqir_amd/rccl.py): stream order is the only dependency.
+                # Checked once against the process group before it is trusted with the timed steps (no N > 1 hardware has run
+                # this path yet); any failure on any rank -> torch's path on all ranks.
                 from tapqir_amd.rccl import RcclDirect
 
-                self.allreduce = RcclDirect(device=dev)
-                self.backend = RcclDirect.backend
+                sys.stdout.flush()
+                saved = os.dup(1)  # (RCCL may print its banner on stdout when a communicator is created: keep it off the JSON line)
+                os.dup2(2, 1)
+                try:
+                    direct = RcclDirect.checked(device=dev)
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
+            if direct is not None:
+                self.allreduce = direct
+                self.backend = direct.backend
             else:
                 # torch's process group (its own stream), left in flight: the engine overlaps it with the next step's local
                 # guide sampling (full-batch steps)
@@ -478,7 +491,8 @@ def roofline_block(pb, ms_per_step, dev):
                "frac": tot_units * sb / t_pu / 1e9 / HBM_PEAK_GBS,
                "kernel": "tq_pixel_unit_kernel<K,P>: the dominant launch of the timed step (render + log-prob + pathwise grads of a "
                          "tile of 64 units, then the per-unit ELBO terms, gradients and Adam of the same units in the same wave; "
-                         f"chosen over two launches by timing both on this box: {[round(t, 4) for t in getattr(eng, 'step_times_ms', [])]} ms per step)",
+                         + (f"chosen over two launches by timing both on this box: {[round(t, 4) for t in eng.step_times_ms]} ms per step)"
+                            if getattr(eng, "step_times_ms", None) else "the default wherever the step qualifies; TAPQIR_AMD_FUSE_UNIT=auto times both forms)"),
                "bytes_per_unit": sb, "units_per_launch": tot_units, "avg_launch_ms": t_pu * 1e3,
                "timing": "HIP events on the launch stream: (launches x [sampling, this kernel]) - (launches x sampling), each an "
                          "uninterrupted sequence, so that the kernel is timed between the launches it runs between in a step",

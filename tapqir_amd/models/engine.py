@@ -140,8 +140,12 @@ class CosmosEngine:
         # full-batch single-GPU steps can run the pixel kernel and the per-unit kernel as ONE launch (pixel_mode =
         # TQ_PIXEL_FUSED_UNIT of tq_cosmos_args): None = not chosen yet -> the first such step times both ways
         # (autotune_fused); TAPQIR_AMD_FUSE_UNIT=0/1 fixes the choice
-        fu = os.environ.get("TAPQIR_AMD_FUSE_UNIT")
-        self.fuse_unit = None if fu is None else fu != "0"
+        # Default: fused wherever the step qualifies (_fusable).  Rounds 1-2 timed both ways on the first step, but four steps
+        # each decide by ~2 % of noise while the fused launch has been 7-15 % ahead on every box since its per-unit phase
+        # became scratch-free (round 3: a mis-tuned run of bench.py measured 0.244 instead of 0.227 ms per c2 step).
+        # TAPQIR_AMD_FUSE_UNIT=auto brings the timing back (three interleaved rounds, best of each).
+        fu = os.environ.get("TAPQIR_AMD_FUSE_UNIT", "1")
+        self.fuse_unit = None if fu == "auto" else fu != "0"
         # minibatch steps with the lazy Adam clock run as ONE launch (include/tapqir_hip.h: tq_cosmos_minibatch_step);
         # TAPQIR_AMD_MB_FUSED=0 keeps the five-launch sequence
         self.fused_minibatch = self.pipelined_tail and os.environ.get("TAPQIR_AMD_MB_FUSED", "1") != "0"
@@ -631,26 +635,28 @@ class CosmosEngine:
                 and self.Nt * self.F * self.C >= self.il_min_units and self.F * self.C >= 256
                 and os.environ.get("TAPQIR_AMD_ROWS", "1") != "0")
 
-    def autotune_fused(self, steps=4):
+    def autotune_fused(self, steps=6, rounds=3):
         """Choose between two launches (pixel kernel, per-unit kernel) and the fused launch for the full-batch steps of
-        this box and dataset by timing ``steps`` real steps each way; parameters, optimiser state and step count are put
-        back afterwards."""
+        this box and dataset by timing real steps each way (``rounds`` interleaved rounds of ``steps`` steps, the best round
+        of each counts); parameters, optimiser state and step count are put back afterwards."""
         if not self._fusable():
             self.fuse_unit = False
             return False
         self.join()
         saved = (self.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_step)
-        times = []
-        for fuse in (False, True):
-            self.fuse_unit = fuse
-            self.step()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(steps):
+        times = [float("inf"), float("inf")]
+        for _ in range(rounds):
+            for k, fuse in enumerate((False, True)):
+                self.fuse_unit = fuse
                 self.step()
-            e1.record()
-            e1.synchronize()
-            times.append(e0.elapsed_time(e1) / steps)
+                self.step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    self.step()
+                e1.record()
+                e1.synchronize()
+                times[k] = min(times[k], e0.elapsed_time(e1) / steps)
         self.join()
         self.params.copy_(saved[0])
         self.exp_avg.copy_(saved[1])

@@ -92,7 +92,9 @@ def make_allreduce(group=None, async_op=False, direct=None):
     if direct:
         from tapqir_amd.rccl import RcclDirect
 
-        return RcclDirect(group)
+        inst = RcclDirect.checked(group)  # None (on every rank) if the direct path does not work here
+        if inst is not None:
+            return inst
 
     def allreduce(gsum: torch.Tensor):
         return dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group, async_op=async_op) if async_op else \

@@ -92,6 +92,31 @@ class RcclDirect:
         self._check(self.lib.ncclAllReduce(p, p, t.numel(), NCCL_FLOAT64, NCCL_SUM, self.comm, C.c_void_p(stream)), "ncclAllReduce")
         return self._handle
 
+    @classmethod
+    def checked(cls, group=None, device=None):
+        """An instance whose all-reduce has been checked once against the process group -- every rank contributes rank + 1 and
+        must read the sum of all ranks -- or None if creating it or the check failed on ANY rank (agreed through the process
+        group, so that all ranks take the same path).  No N > 1 hardware has run this path yet: callers fall back to
+        ``torch.distributed.all_reduce``."""
+        import sys
+
+        import torch.distributed as dist
+
+        inst, ok = None, 1.0
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        try:
+            inst = cls(group, dev)
+            t = torch.full((6,), float(inst.rank + 1), dtype=torch.float64, device=dev)
+            inst(t)
+            torch.cuda.synchronize(dev)
+            ok = float(bool((t == inst.world * (inst.world + 1) / 2).all()))
+        except Exception as err:  # noqa: BLE001
+            print(f"tapqir_amd.rccl: direct all-reduce unavailable ({err}); using torch.distributed.all_reduce", file=sys.stderr)
+            ok = 0.0
+        flag = torch.tensor([ok], device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return inst if float(flag[0]) >= 1.0 else None
+
     def close(self):
         if self.comm:
             torch.cuda.synchronize(self.device)
