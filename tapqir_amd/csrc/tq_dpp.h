@@ -16,6 +16,17 @@ __device__ __forceinline__ float tq_group_sum16(float v) {
   return v;
 }
 
+// sum over the LANES (16 or 64) lanes of a unit, in every lane: the DPP row sum, then -- a unit per wave -- the four rows
+template <int LANES>
+__device__ __forceinline__ float tq_group_sum(float v) {
+  v = tq_group_sum16(v);
+  if (LANES == 64) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+  }
+  return v;
+}
+
 // two FP32 values per lane that the compiler maps onto packed instructions (two operations per lane and issue slot)
 typedef float tq_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ tq_f2 tq2(float a) { return (tq_f2){a, a}; }

@@ -31,10 +31,10 @@
 #include "tq_ksmogn_dev.h"
 #include "tq_ksmogn_il2.h"
 
-template <int K, bool ONE_OFFSET, bool BWD>
+template <int K, bool ONE_OFFSET, bool BWD, int LANES = TQ_LANES_PER_UNIT>
 __global__ __launch_bounds__(TQ_BLOCK, TQ_PIX_WAVES) void tq_ksmogn_kernel(const tq_ksmogn_args a, const int64_t B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  tq_ksmogn_tile16<K, ONE_OFFSET, BWD>(a, B, (int64_t)blockIdx.x, smem);
+  tq_ksmogn_tile16<K, ONE_OFFSET, BWD, LANES>(a, B, (int64_t)blockIdx.x, smem);
 }
 
 
@@ -786,6 +786,22 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
   if (!a.images) {
     tq_set_error("tq_ksmogn_log_prob: images is NULL and the interleaved kernel does not apply to this batch");
     return TQ_ERR_ARG;
+  }
+  if (!ONE && a.O >= 8) {
+    // offset histograms: a wave per unit (the offset loop makes a unit ~O times the work of the single-offset form, and a
+    // gathered batch is small: at 16 lanes per unit a 10 x 512 minibatch fills 1.25 waves per SIMD)
+    static const bool wide = [] {
+      const char* e = getenv("TAPQIR_AMD_WIDE_HIST");
+      return !(e && e[0] == '0');
+    }();
+    if (wide) {
+      constexpr int UNITS = TQ_BLOCK / 64;
+      const dim3 gridw((unsigned)((B + UNITS - 1) / UNITS)), blockw(TQ_BLOCK);
+      const size_t ldsw = sizeof(float) * tq_tile16_lds_floats(a.P, K, a.O, UNITS);
+      if (bwd) hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, true, 64>), gridw, blockw, ldsw, st, a, B);
+      else hipLaunchKernelGGL((tq_ksmogn_kernel<K, false, false, 64>), gridw, blockw, ldsw, st, a, B);
+      return launch_status("tq_ksmogn_kernel (64 lanes per unit)");
+    }
   }
   const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK)), block(TQ_BLOCK);
   const size_t lds = sizeof(float) * tq_tile16_lds_floats(a.P, K, a.O);

@@ -255,7 +255,7 @@ __device__ __forceinline__ void tq_load_weights(const tq_ksmogn_args& a, int64_t
 // =============================================================================================
 // 16 lanes per unit
 // =============================================================================================
-template <int K, bool ONE_OFFSET, bool BWD, bool FAST>
+template <int K, bool ONE_OFFSET, bool BWD, bool FAST, int LANES = TQ_LANES_PER_UNIT>
 __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_args& a,
                                               const float* __restrict__ s_tile, const float* __restrict__ s_fac,
                                               int r, int P, int npix, float b, const float* amph, float g, float rg,
@@ -272,7 +272,7 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
       tq_offset_info(a.offset_samples, a.offset_logits, a.O, &h);
     }
   }
-  for (int pix = r; pix < npix; pix += TQ_LANES_PER_UNIT) {
+  for (int pix = r; pix < npix; pix += LANES) {
     const int j = (int)(((uint32_t)pix * magic) >> 20);
     const int ic = pix - j * P;
     const float D = s_tile[pix];
@@ -294,17 +294,21 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
 // tq_tile16_lds_floats(P, K) floats.  Called by tq_ksmogn_kernel (tq_ksmogn.hip) and by the single-launch minibatch step
 // (tq_cosmos.hip), which runs it between its sampling and per-unit phases.
 #define TQ_OFFTAB_MAX 2048  /* offsets whose table the workgroup keeps in LDS (28 KB); longer histograms read global memory */
-__host__ __device__ inline size_t tq_tile16_lds_floats(int P, int K, int O = 1) {
-  return (size_t)TQ_UNITS_PER_BLOCK * (tq_tile_stride(P * P) + 2 * K * TQ_MAX_P) + ((O > 1 && O <= TQ_OFFTAB_MAX) ? 4 + 3 * (size_t)O : 0);
+__host__ __device__ inline size_t tq_tile16_lds_floats(int P, int K, int O = 1, int units = TQ_UNITS_PER_BLOCK) {
+  return (size_t)units * (tq_tile_stride(P * P) + 2 * K * TQ_MAX_P) + ((O > 1 && O <= TQ_OFFTAB_MAX) ? 4 + 3 * (size_t)O : 0);
 }
-template <int K, bool ONE_OFFSET, bool BWD>
+// LANES lanes per unit (16: sixteen units per workgroup of 256 threads; 64: four units, a wave each -- the offset-histogram
+// form of gathered batches, whose offset loop is long enough to want every wave slot of the chip: a 10 x 512 minibatch is
+// 5120 units = 1280 waves at 16 lanes per unit, 5120 at 64).
+template <int K, bool ONE_OFFSET, bool BWD, int LANES = TQ_LANES_PER_UNIT>
 __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const int64_t B, const int64_t blk, float* smem) {
   constexpr int M = 1 << K;
+  constexpr int UNITS = TQ_BLOCK / LANES;
 
   const int tid = threadIdx.x;
-  const int grp = tid >> 4;
-  const int r = tid & 15;
-  const int64_t i_raw = blk * TQ_UNITS_PER_BLOCK + grp;
+  const int grp = tid / LANES;
+  const int r = tid % LANES;
+  const int64_t i_raw = blk * UNITS + grp;
   const bool live = i_raw < B;
   const int64_t i = live ? i_raw : (B - 1);  // dead groups shadow the last unit, stores masked
 
@@ -313,7 +317,7 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   const int npix = P * P;
   const int stride = tq_tile_stride(npix);
   float* s_tile = smem + grp * stride;
-  float* s_fac = smem + TQ_UNITS_PER_BLOCK * stride + grp * (2 * K * TQ_MAX_P);
+  float* s_fac = smem + UNITS * stride + grp * (2 * K * TQ_MAX_P);
   // (B < 2^31 is checked on the host; 32-bit arithmetic, and no division at all for a contiguous batch)
   const uint32_t iu = (uint32_t)i;
   int n;
@@ -335,9 +339,9 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   if ((npix & 3) == 0) {
     const float4* t4 = reinterpret_cast<const float4*>(tile);
     const int n4 = npix >> 2;
-    for (int e = r; e < n4; e += TQ_LANES_PER_UNIT) *reinterpret_cast<float4*>(s_tile + 4 * e) = t4[e];
+    for (int e = r; e < n4; e += LANES) *reinterpret_cast<float4*>(s_tile + 4 * e) = t4[e];
   } else {
-    for (int e = r; e < npix; e += TQ_LANES_PER_UNIT) s_tile[e] = tile[e];
+    for (int e = r; e < npix; e += LANES) s_tile[e] = tile[e];
   }
 
   const float g = a.gain[0];
@@ -356,7 +360,7 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
     const float inv2v = 0.5f * TQ_FRCP(wk[k] * wk[k]);
     amph[k] = hk[k] * inv2v * (1.0f / TQ_PI);  // h / (2 pi w^2)
     // separable factors: lanes 0..15 fill the 2P entries of spot k
-    for (int e = r; e < 2 * P; e += TQ_LANES_PER_UNIT) {
+    for (int e = r; e < 2 * P; e += LANES) {
       const int axis = e >= P;
       const int p = e - axis * P;
       const float d = (float)p - (axis ? cy[k] : cx[k]);
@@ -370,7 +374,7 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   // offset histogram: extrema and per-offset constants once per workgroup (every thread of the workgroup is here)
   float* s_off = nullptr;
   if (!ONE_OFFSET && a.O <= TQ_OFFTAB_MAX) {
-    s_off = smem + TQ_UNITS_PER_BLOCK * (stride + 2 * K * TQ_MAX_P);
+    s_off = smem + UNITS * (stride + 2 * K * TQ_MAX_P);
     if (tid < 64) {  // min / max are exact: the values of tq_offset_info
       float lo = INFINITY, hi = -INFINITY, lw = -INFINITY, lwn = INFINITY;
       for (int o = tid; o < a.O; o += 64) {
@@ -409,34 +413,34 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
   tq_acc_zero<K>(A);
   // alpha(m) >= background / gain for every combination and pixel: one wave-uniform test picks
   // the branch-free loop (one-term Binet correction valid) or the general one
-  if (__all(b * rg >= TQ_FAST_ALPHA)) tq_pixel_loop<K, ONE_OFFSET, BWD, true>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, s_off);
-  else tq_pixel_loop<K, ONE_OFFSET, BWD, false>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, s_off);
+  if (__all(b * rg >= TQ_FAST_ALPHA)) tq_pixel_loop<K, ONE_OFFSET, BWD, true, LANES>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, s_off);
+  else tq_pixel_loop<K, ONE_OFFSET, BWD, false, LANES>(A, a, s_tile, s_fac, r, P, npix, b, amph, g, rg, ln_g, W, s_off);
 
   // ---- reduce over the unit's 16 lanes, assemble and store ------------------------------------------
 #pragma unroll
   for (int mi = 0; mi < M; ++mi) {
-    A.ll[mi] = tq_group_sum16(A.ll[mi]);
+    A.ll[mi] = tq_group_sum<LANES>(A.ll[mi]);
     if (ONE_OFFSET) {
-      A.sl[mi] = tq_group_sum16(A.sl[mi]);
-      A.sS[mi] = tq_group_sum16(A.sS[mi]);
+      A.sl[mi] = tq_group_sum<LANES>(A.sl[mi]);
+      A.sS[mi] = tq_group_sum<LANES>(A.sS[mi]);
     }
   }
   if (BWD) {
-    A.acc_b = tq_group_sum16(A.acc_b);
-    if (!ONE_OFFSET) A.acc_g = tq_group_sum16(A.acc_g);
+    A.acc_b = tq_group_sum<LANES>(A.acc_b);
+    if (!ONE_OFFSET) A.acc_g = tq_group_sum<LANES>(A.acc_g);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      A.S0[k] = tq_group_sum16(A.S0[k]);
-      A.Sx[k] = tq_group_sum16(A.Sx[k]);
-      A.Sy[k] = tq_group_sum16(A.Sy[k]);
-      A.Sr[k] = tq_group_sum16(A.Sr[k]);
+      A.S0[k] = tq_group_sum<LANES>(A.S0[k]);
+      A.Sx[k] = tq_group_sum<LANES>(A.Sx[k]);
+      A.Sy[k] = tq_group_sum<LANES>(A.Sy[k]);
+      A.Sr[k] = tq_group_sum<LANES>(A.Sr[k]);
     }
   }
   float S_v = 0.0f;
   bool bad = false;
   if (ONE_OFFSET) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) A.SN[k] = tq_group_sum16(A.SN[k]);
+    for (int k = 0; k < K; ++k) A.SN[k] = tq_group_sum<LANES>(A.SN[k]);
     S_v = a.pixstats[u];
     const float S_lv = a.pixstats[a.stats_stride + u];
     bad = a.pixstats[2 * a.stats_stride + u] > 0.0f;

@@ -714,8 +714,10 @@ class CosmosEngine:
         minibatch = bool(a.zero_grad)
         # Adam on the local block is fused into the unit kernel: full batches, and minibatches with the lazy clock
         a.fuse_adam = int(not minibatch or self.lazy_adam)
+        # (offset histograms stay in the single launch: the staged sequence with the wave-per-unit likelihood kernel measured
+        # 0.150 against 0.162 ms at O = 50 -- TAPQIR_AMD_MB_HIST_STAGED=1 -- not worth a second path through the step)
         one_launch = (minibatch and self.lazy_adam and self.fused_minibatch and allreduce is None and not self.crosstalk
-                      and a.fb * self.C >= 16)
+                      and a.fb * self.C >= 16 and not (self.O >= 8 and os.environ.get("TAPQIR_AMD_MB_HIST_STAGED") == "1"))
         if minibatch and self.lazy_adam:
             if not self._stale:
                 self._last_step.fill_(self.adam_step)  # every unit is current: start the clock here

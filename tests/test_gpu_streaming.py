@@ -80,6 +80,9 @@ def test_model_fit_with_forced_budget(tmp_path, monkeypatch):
         K, device = 2, torch.device("cpu")
 
     data = simulate(_M, 8, 30, 1, 14, seed=4, params=TEST_PARAMS)
+    # the same subsample sequence on both sides: host draws (a resident fit would otherwise draw its subsamples on the device,
+    # CosmosEngine.step_subsampled, which a streamed engine cannot: it gathers the batch's AOIs on the host)
+    monkeypatch.setenv("TAPQIR_AMD_DEVICE_SUBSAMPLE", "0")
     fits = {}
     for mode in ("resident", "streamed"):
         path = tmp_path / mode
