@@ -12,16 +12,21 @@
 #include <cstdlib>
 
 #include "tq_bodies.h"
+#include "tq_dpp.h"
 
 void tq_set_error(const char* msg);
 
 #define TQ_UNIT_BLOCK 256
 #define TQ_MAX_NGSUM (3 + 3 * TQ_MAXQ)  // >= 3 + 3*2 + 2*2 of the crosstalk model
 
+// sum over the wave (every lane active), in every lane: DPP adds inside the four rows of 16 lanes, then the four row sums
+// read as scalars -- no LDS crossbar (six ds_bpermute per sum in the shuffle form; the fused pixel + per-unit kernel ends
+// every wave with 22 such sums)
 __device__ __forceinline__ float tq_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v = tq_group_sum16(v);
+  const int b = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 
 // ---- sampling ------------------------------------------------------------------------------------------

@@ -291,7 +291,7 @@ TQ_HD void tq_cosmos_unit(const TqUnitIn<K>& in, const TqGlobals& G, const TqSit
   for (int k = 0; k < K; ++k) {
     const float tx = (in.x[k] + H) * r2H, ty = (in.y[k] + H) * r2H;
     const float ex = 2.0f * tx - 1.0f, ey = 2.0f * ty - 1.0f;
-    tsum[k] = log1pf(-ex * ex) + log1pf(-ey * ey);  // ln[4 tx (1-tx)] + ln[4 ty (1-ty)]
+    tsum[k] = tq_log1p_fast(-ex * ex) + tq_log1p_fast(-ey * ey);  // ln[4 tx (1-tx)] + ln[4 ty (1-ty)]
     sxy[k] = (cs - 1.0f) * tsum[k] - 2.0f * G.lnB_s + lu;
     dsx[k] = (cs - 1.0f) * (TQ_FRCP(tx) - TQ_FRCP(1.0f - tx)) * r2H;
     dsy[k] = (cs - 1.0f) * (TQ_FRCP(ty) - TQ_FRCP(1.0f - ty)) * r2H;
