@@ -627,6 +627,15 @@ def worker(args):
         "elbo_steps_per_sec": h["elbo_steps_per_sec"], "final_elbo": h["final_elbo"],
     }
 
+    if world == 1 and args.profile_minibatch > 0:
+        # profiling runs: N steps at the reference's default minibatch (10 x 512, fresh subsample every step), untimed
+        nb, fb = min(10, pb.N), min(512, pb.F)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        for _ in range(args.profile_minibatch):
+            eng.step(torch.randperm(pb.N, generator=g)[:nb], torch.randperm(pb.F, generator=g)[:fb])
+        eng.join()
+        torch.cuda.synchronize()
+
     if world == 1 and not args.quick:
         # ---- roofline of the dominant kernel (same parameter regime as the headline steps) -----------
         out["roofline"] = roofline_block(pb, h["ms_per_step"], dev)
@@ -704,6 +713,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--quick", action="store_true", help="headline only (no minibatch / roofline / CPU legs)")
     ap.add_argument("--trained-steps", type=int, default=4000, help="steps before the trained-regime leg (0 = skip)")
+    ap.add_argument("--profile-minibatch", type=int, default=0, help="untimed default-minibatch steps after the headline (profiling runs)")
     ap.add_argument("--pre-steps", type=int, default=0, help="untimed full-batch steps before the headline (profiling the trained regime)")
     ap.add_argument("--offsets", default="sim", choices=["sim", "hist"])
     ap.add_argument("--model", default=None, choices=["cosmos", "crosstalk"], help="crosstalk = --config c4")

@@ -37,7 +37,7 @@ if [[ $S == *pmc* ]]; then
   STEPOUT=r03/steppmc_c3 STEPARGS="--config c3" bash $R/scripts/gpu_step_pmc.sh > $O/steppmc_c3.log 2>&1; cp $O/steppmc_c3/summary.txt $O/pmc_summary_step_c3shard.txt
   STEPOUT=r03/steppmc_c4 STEPARGS="--config c4" bash $R/scripts/gpu_step_pmc.sh > $O/steppmc_c4.log 2>&1; cp $O/steppmc_c4/summary.txt $O/pmc_summary_step_c4.txt
   STEPOUT=r03/steppmc_c5 STEPARGS="--config c5" bash $R/scripts/gpu_step_pmc.sh > $O/steppmc_c5.log 2>&1; cp $O/steppmc_c5/summary.txt $O/pmc_summary_step_c5shard.txt
-  STEPOUT=r03/steppmc_hist STEPARGS="--offsets hist" bash $R/scripts/gpu_step_pmc.sh > $O/steppmc_hist.log 2>&1; cp $O/steppmc_hist/summary.txt $O/pmc_summary_step_hist50.txt
+  STEPOUT=r03/steppmc_hist STEPARGS="--offsets hist --profile-minibatch 100" bash $R/scripts/gpu_step_pmc.sh > $O/steppmc_hist.log 2>&1; cp $O/steppmc_hist/summary.txt $O/pmc_summary_step_hist50.txt  # (full-batch steps + 100 minibatch steps 10 x 512)
   cd $R
   python3 scripts/make_step_traffic.py $O/pmc_step_traffic.json c2=$O/pmc_summary_step.txt:400000 c2_trained=$O/pmc_summary_step_trained.txt:400000 \
       c3=$O/pmc_summary_step_c3shard.txt:1600000 \
