@@ -1406,35 +1406,18 @@ static int launch_likelihood(const tq_cosmos_args* a, void* stream) {
   return tq_ksmogn_log_prob(&k, stream);
 }
 
-// Resident single-wave workgroups of the fused launch per CU (8 = two per SIMD, what its registers allow).  The launch never
-// uses LDS: a dynamic LDS REQUEST caps the residency (160 KB per CU).  Why cap it: a launch of T tiles on S wave slots runs
-// ceil(T / S) rounds and the last one can be nearly empty -- c2 is 6250 tiles on 2048 slots: three full rounds and 106 tiles
-// that take ~25 us with the chip 5 % busy.  (experiment switch: TAPQIR_AMD_FUSED_WGS_PER_CU)
-static size_t tq_fused_occupancy_lds(int64_t tiles) {
-  static const int forced = [] {
-    const char* e = getenv("TAPQIR_AMD_FUSED_WGS_PER_CU");
-    return e ? atoi(e) : 0;
-  }();
-  (void)tiles;
-  const int n = forced;
-  if (n <= 0 || n >= 8) return 0;
-  // more than 160 KB / (n + 1), at most 160 KB / n
-  return (size_t)((160 * 1024) / n) & ~(size_t)511;
-}
-
 static int launch_pixel_unit(const tq_cosmos_args* a, void* stream) {
   const int64_t B = tq_batch_units(*a);
 
   const tq_ksmogn_args k = cosmos_ksmogn_args(a);
   const dim3 grid((unsigned)((B + 63) / 64)), block(64);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = tq_fused_occupancy_lds((int64_t)grid.x);
   if (a->K == 1) {
-    if (a->P == 14) hipLaunchKernelGGL((tq_pixel_unit_kernel<1, 14>), grid, block, lds, st, k, *a, B);
-    else hipLaunchKernelGGL((tq_pixel_unit_kernel<1, 20>), grid, block, lds, st, k, *a, B);
+    if (a->P == 14) hipLaunchKernelGGL((tq_pixel_unit_kernel<1, 14>), grid, block, 0, st, k, *a, B);
+    else hipLaunchKernelGGL((tq_pixel_unit_kernel<1, 20>), grid, block, 0, st, k, *a, B);
   } else {
-    if (a->P == 14) hipLaunchKernelGGL((tq_pixel_unit_kernel<2, 14>), grid, block, lds, st, k, *a, B);
-    else hipLaunchKernelGGL((tq_pixel_unit_kernel<2, 20>), grid, block, lds, st, k, *a, B);
+    if (a->P == 14) hipLaunchKernelGGL((tq_pixel_unit_kernel<2, 14>), grid, block, 0, st, k, *a, B);
+    else hipLaunchKernelGGL((tq_pixel_unit_kernel<2, 20>), grid, block, 0, st, k, *a, B);
   }
   return check_launch("tq_pixel_unit_kernel");
 }
