@@ -27,3 +27,9 @@ for it in range(300):
     else: e.step(torch.randperm(400, generator=g)[:10], torch.randperm(1000, generator=g)[:512])
 e.join(); torch.cuda.synchronize()
 print("minibatch 40000 + mixed 300 steps", round(time.time() - t0, 2), "s; ELBO", float(e.elbo_out[0]), "finite", bool(torch.isfinite(e.params).all()))
+# device-drawn subsamples (the launch of step t draws the subsample of step t + 1)
+t0 = time.time()
+for it in range(20000):
+    assert e.step_subsampled(10, 512, g)
+e.join(); torch.cuda.synchronize()
+print("device-subsampled 20000 steps", round(time.time() - t0, 2), "s; ELBO", float(e.elbo_out[0]), "finite", bool(torch.isfinite(e.params).all()))
