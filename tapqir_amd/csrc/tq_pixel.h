@@ -212,6 +212,43 @@ TQ_HD void tq_pix_multi_offset_tab(float D, const float* mu, const float* tab, i
   }
   // branch-free: an offset at or above the pixel contributes t = 0 (its logarithm is taken of a clamped argument and
   // selected away), so that the loads and transcendentals of consecutive offsets overlap
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (M % 2 == 0) {
+    // the combinations in pairs on packed (two results per lane and issue slot) instructions: per offset and pair one
+    // v_pk_fma for the exponent, two exp2, and -- with the backward -- two v_pk_fma and one v_pk_add for the three sums
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a2[M / 2], c2[M / 2], T0[M / 2], T1[M / 2], T2[M / 2];
+    for (int p = 0; p < M / 2; ++p) {
+      a2[p] = (f2){a[2 * p], a[2 * p + 1]};
+      c2[p] = (f2){c[2 * p], c[2 * p + 1]};
+      T0[p] = T1[p] = T2[p] = (f2){0.0f, 0.0f};
+    }
+#pragma unroll 4
+    for (int o = 0; o < O; ++o) {
+      const float v = D - tab[3 * o];
+      const bool on = v > 0.0f;
+      const float dl = TQ_FLOG2((on ? v : vhi) * rvhi);
+      const float dd = tab[3 * o + 1];
+      const float db = tab[3 * o + 2];
+      const f2 dl2 = (f2){dl, dl}, dd2 = (f2){dd, dd}, db2 = (f2){db, db};
+      for (int p = 0; p < M / 2; ++p) {
+        const f2 ex = (a2[p] * dl2 + c2[p]) + db2;
+        const f2 e = (f2){TQ_FEXP2(ex.x), TQ_FEXP2(ex.y)};
+        const f2 t = on ? e : (f2){0.0f, 0.0f};
+        T0[p] += t;
+        if (BWD) {
+          T1[p] += t * dl2;
+          T2[p] += t * dd2;
+        }
+      }
+    }
+    for (int p = 0; p < M / 2; ++p) {
+      S0[2 * p] = T0[p].x; S0[2 * p + 1] = T0[p].y;
+      S1[2 * p] = T1[p].x; S1[2 * p + 1] = T1[p].y;
+      S2[2 * p] = T2[p].x; S2[2 * p + 1] = T2[p].y;
+    }
+  } else
+#endif
 #pragma unroll 4
   for (int o = 0; o < O; ++o) {
     const float v = D - tab[3 * o];
