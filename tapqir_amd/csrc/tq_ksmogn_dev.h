@@ -293,9 +293,9 @@ __device__ __forceinline__ void tq_pixel_loop(TqPixAcc<K>& A, const tq_ksmogn_ar
 // The 16 units [blk * 16, blk * 16 + 16) of the batch by one workgroup of 256 threads; `smem` holds
 // tq_tile16_lds_floats(P, K) floats.  Called by tq_ksmogn_kernel (tq_ksmogn.hip) and by the single-launch minibatch step
 // (tq_cosmos.hip), which runs it between its sampling and per-unit phases.
-#define TQ_OFFTAB_MAX 2048  /* offsets whose table the workgroup keeps in LDS (28 KB); longer histograms read global memory */
+#define TQ_OFFTAB_MAX 2048  /* offsets whose table the workgroup keeps in LDS (16 B each: 32 KB); longer histograms read global memory */
 __host__ __device__ inline size_t tq_tile16_lds_floats(int P, int K, int O = 1, int units = TQ_UNITS_PER_BLOCK) {
-  return (size_t)units * (tq_tile_stride(P * P) + 2 * K * TQ_MAX_P) + ((O > 1 && O <= TQ_OFFTAB_MAX) ? 4 + 3 * (size_t)O : 0);
+  return (size_t)units * (tq_tile_stride(P * P) + 2 * K * TQ_MAX_P) + ((O > 1 && O <= TQ_OFFTAB_MAX) ? 4 + 4 * (size_t)O : 0);
 }
 // LANES lanes per unit (16: sixteen units per workgroup of 256 threads; 64: four units, a wave each -- the offset-histogram
 // form of gathered batches, whose offset loop is long enough to want every wave slot of the chip: a 10 x 512 minibatch is
@@ -395,9 +395,9 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
     for (int o = tid; o < a.O; o += TQ_BLOCK) {  // the expressions of tq_pix_multi_offset
       const float sv = a.offset_samples[o];
       const float dd = sv - dmin;
-      s_off[4 + 3 * o] = sv;
-      s_off[4 + 3 * o + 1] = dd;
-      s_off[4 + 3 * o + 2] = (a.offset_logits[o] * TQ_LOG2E - lw2max) + beta2 * dd;
+      s_off[4 + 4 * o] = sv;
+      s_off[4 + 4 * o + 1] = dd;
+      s_off[4 + 4 * o + 2] = (a.offset_logits[o] * TQ_LOG2E - lw2max) + beta2 * dd;
     }
     __syncthreads();
   }

@@ -180,8 +180,8 @@ TQ_HD void tq_pix_multi_offset(float D, const float* mu, const float* samples, c
   for (int mi = 0; mi < M; ++mi) tq_mo_finish(FAST, mu[mi], vs[mi], vhi, S0[mi], S1[mi], S2[mi], h, g, rg, ln_g, &lp[mi], &da[mi], &gq[mi]);
 }
 
-// The same with the per-offset constants taken from a table tab[3 o] = {delta_o, delta_o - delta_min, log2 w_o - log2 w_max +
-// beta (delta_o - delta_min) log2 e} (the expressions of the loop above, formed once per workgroup: the 16-lane kernel keeps
+// The same with the per-offset constants taken from a table tab[4 o] = {delta_o, delta_o - delta_min, log2 w_o - log2 w_max +
+// beta (delta_o - delta_min) log2 e, unused} (16 bytes per offset: one LDS read) (the expressions of the loop above, formed once per workgroup: the 16-lane kernel keeps
 // the table in LDS -- as two scalar loads from global memory per offset and pixel, the offset loop of a minibatch step
 // with a 50-value histogram spent most of its time waiting for them).
 template <int M, bool BWD, bool FAST>
@@ -200,7 +200,7 @@ TQ_HD void tq_pix_multi_offset_tab(float D, const float* mu, const float* tab, i
   if (!(vlo > 0.0f)) {  // some offsets are masked: the smallest valid v
     vlo = vhi;
     for (int o = 0; o < O; ++o) {
-      const float v = D - tab[3 * o];
+      const float v = D - tab[4 * o];
       if (v > 0.0f) vlo = fminf(vlo, v);
     }
   }
@@ -223,18 +223,37 @@ TQ_HD void tq_pix_multi_offset_tab(float D, const float* mu, const float* tab, i
       c2[p] = (f2){c[2 * p], c[2 * p + 1]};
       T0[p] = T1[p] = T2[p] = (f2){0.0f, 0.0f};
     }
+    if (__builtin_amdgcn_ballot_w64(!(D - h.dmax > 0.0f)) == 0) {
+      // no pixel of this wave reaches down to the largest offset (every real camera image: the offsets are its dark level):
+      // no masks
+#pragma unroll 4
+      for (int o = 0; o < O; ++o) {
+        const float4 e4 = *reinterpret_cast<const float4*>(tab + 4 * o);
+        const float dl = TQ_FLOG2((D - e4.x) * rvhi);
+        const f2 dl2 = (f2){dl, dl}, dd2 = (f2){e4.y, e4.y}, db2 = (f2){e4.z, e4.z};
+        for (int p = 0; p < M / 2; ++p) {
+          const f2 ex = (a2[p] * dl2 + c2[p]) + db2;
+          const f2 t = (f2){TQ_FEXP2(ex.x), TQ_FEXP2(ex.y)};
+          T0[p] += t;
+          if (BWD) {
+            T1[p] += t * dl2;
+            T2[p] += t * dd2;
+          }
+        }
+      }
+    } else
 #pragma unroll 4
     for (int o = 0; o < O; ++o) {
-      const float v = D - tab[3 * o];
+      const float4 e4 = *reinterpret_cast<const float4*>(tab + 4 * o);
+      const float v = D - e4.x;
       const bool on = v > 0.0f;
       const float dl = TQ_FLOG2((on ? v : vhi) * rvhi);
-      const float dd = tab[3 * o + 1];
-      const float db = tab[3 * o + 2];
-      const f2 dl2 = (f2){dl, dl}, dd2 = (f2){dd, dd}, db2 = (f2){db, db};
+      const float dd = e4.y;
+      const float dbe = on ? e4.z : -INFINITY;  // exp2(-inf) = 0: a masked offset drops out of all three sums (dl is finite)
+      const f2 dl2 = (f2){dl, dl}, dd2 = (f2){dd, dd}, db2 = (f2){dbe, dbe};
       for (int p = 0; p < M / 2; ++p) {
         const f2 ex = (a2[p] * dl2 + c2[p]) + db2;
-        const f2 e = (f2){TQ_FEXP2(ex.x), TQ_FEXP2(ex.y)};
-        const f2 t = on ? e : (f2){0.0f, 0.0f};
+        const f2 t = (f2){TQ_FEXP2(ex.x), TQ_FEXP2(ex.y)};
         T0[p] += t;
         if (BWD) {
           T1[p] += t * dl2;
@@ -251,11 +270,11 @@ TQ_HD void tq_pix_multi_offset_tab(float D, const float* mu, const float* tab, i
 #endif
 #pragma unroll 4
   for (int o = 0; o < O; ++o) {
-    const float v = D - tab[3 * o];
+    const float v = D - tab[4 * o];
     const bool on = v > 0.0f;
     const float dl = TQ_FLOG2((on ? v : vhi) * rvhi);
-    const float dd = tab[3 * o + 1];
-    const float db = tab[3 * o + 2];
+    const float dd = tab[4 * o + 1];
+    const float db = tab[4 * o + 2];
     for (int mi = 0; mi < M; ++mi) {
       const float e = TQ_FEXP2((a[mi] * dl + c[mi]) + db);
       const float t = on ? e : 0.0f;
