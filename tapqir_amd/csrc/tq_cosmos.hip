@@ -444,9 +444,24 @@ static bool tq_rows_layout(const tq_cosmos_args& a) {
   return enabled && a.fuse_adam && !a.ndx && !a.fdx && a.nb == a.Nt && a.fb == a.F && a.F * a.C >= TQ_UNIT_BLOCK;
 }
 
+// Units per workgroup (= per row of partial sums) of the single-launch minibatch step: 16, one 16-lane group each -- or 20,
+// the last four with a wave each, when that takes fewer rounds of pixel iterations on the chip's 256 CUs.  A workgroup
+// keeps one wave per SIMD busy for 13 iterations of P = 14 (196 pixels on 16 lanes), 17 with 20 units (+ 4: 196 pixels on 64
+// lanes); a CU that hosts two workgroups takes twice as long, and the default 10 x 512 minibatch is 320 workgroups of 16
+// units -- 64 CUs with two, 26 iterations on the critical path -- but 256 of 20: 17.  A pure function of the batch geometry
+// (TAPQIR_AMD_MB_UNITS = 16 / 20 overrides): the launch that runs the pending tail of the step calls it again.
+static int tq_mb_upr(const tq_cosmos_args& a) {
+  const char* e = getenv("TAPQIR_AMD_MB_UNITS");  // (read at every call: tests switch it inside one process)
+  const int forced = e ? atoi(e) : 0;
+  if ((int64_t)a.fb * a.C < 20 || forced == 16) return 16;
+  if (forced == 20) return 20;
+  const int64_t B = tq_batch_units(a);
+  const int64_t r16 = ((B + 15) / 16 + 255) / 256, r20 = ((B + 19) / 20 + 255) / 256;
+  return 17 * r20 < 13 * r16 ? 20 : 16;
+}
 // has_prev code of a pending step for the kernels that run its tail
 static int tq_prev_code(const tq_cosmos_args& prev) {
-  if (prev.tail_kind == TQ_TAIL_ROWS16) return 4;
+  if (prev.tail_kind == TQ_TAIL_ROWS16) return tq_mb_upr(prev) == 20 ? 7 : 4;
   return tq_rows_layout(prev) ? 3 : 1;
 }
 // units per row of a step with rows (codes 3 / 4): 16 (single-launch minibatch step), 64 (fused pixel + per-unit
@@ -522,6 +537,7 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
 #define TQ_GRP_UNITS 4096
 #define TQ_GRP_AOIS (TQ_GRP_UNITS / TQ_UNIT_BLOCK + 1)   /* AOIs a group can touch (F * C >= TQ_UNIT_BLOCK) */
 #define TQ_GGROW (2 * 16 + TQ_GRP_AOIS * 2 * TQ_MAXQ)    /* floats of a group row: 16 doubles, then 2 * TQ_MAXQ floats per AOI */
+#define TQ_SYNC_CLAIM 60                                 /* word that names the workgroup running the tail of a minibatch launch (tail_last) */
 #define TQ_SYNC_GROUPS 40                                /* word of tq_cosmos_args.sync that counts the finished groups */
 __host__ __device__ __forceinline__ int64_t tq_grp_count(int64_t B) { return (B + TQ_GRP_UNITS - 1) / TQ_GRP_UNITS; }
 // group rows follow the rows in blk_part (16-byte aligned)
@@ -662,12 +678,14 @@ __device__ __forceinline__ void tq_rows_column_sums(const tq_cosmos_args& a, int
 
 // Tail of a step whose per-unit kernel wrote such rows (ONE workgroup of 256 threads): per-AOI sites from the rows that
 // overlap the AOI, cross-unit sums in fp64, global sites and the total ELBO.
-// UPR = units per row: TQ_UNIT_BLOCK (tq_unit_rows_kernel) or 16 (the single-launch minibatch step)
+// UPR = units per row: TQ_UNIT_BLOCK (tq_unit_rows_kernel) or 16 (the single-launch minibatch step, whose rows hold `mb_upr`
+// = 16 or 20 units: the host's tq_mb_upr)
 template <int UPR_T>
-__device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+__device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e,
+                                                            const int mb_upr = 16) {
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
   const int64_t B = tq_batch_units(a);
-  const uint32_t UPR = UPR_T == 16 ? 16u : (uint32_t)tq_rows_upr(a);  // (one instance serves rows of 64 and of 256)
+  const uint32_t UPR = UPR_T == 16 ? (uint32_t)mb_upr : (uint32_t)tq_rows_upr(a);  // (one instance serves rows of 64 and of 256)
   const int64_t nrows = (B + UPR - 1) / UPR;
   const uint32_t FC = (uint32_t)(a.fb * a.C);  // units of one AOI of the batch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -926,7 +944,7 @@ __global__ __launch_bounds__(256) void tq_rows_sums_kernel(const tq_cosmos_args 
 __global__ __launch_bounds__(256) void tq_rows_reduce_globals_kernel(const tq_cosmos_args a, const int upr) {
   __shared__ double s_w[4][TQ_MAX_NGSUM];
   __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
-  if (upr == 16) tq_rows_reduce_globals_body<16>(a, s_w, s_e);
+  if (upr <= 20) tq_rows_reduce_globals_body<16>(a, s_w, s_e, upr);
   else tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(a, s_w, s_e);
 }
 
@@ -1049,16 +1067,45 @@ __device__ __forceinline__ void tq_draw_subsample(uint64_t* buf, uint64_t seed, 
 #define TQ_SITE_SUBSAMPLE_N 0xA00u
 #define TQ_SITE_SUBSAMPLE_F 0xA01u
 
-template <int K, bool ONE>
+#ifdef TQ_MB_STAMPS
+// (diagnostic) where a workgroup runs: XCC (4 bits) | SE, SH, CU of HW_ID (8 bits) | block (10 bits) | ticket (10 bits)
+__device__ __forceinline__ unsigned long long tq_where(unsigned block, int ticket) {
+  uint32_t hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return ((unsigned long long)(xcc & 15) << 28) | (((hw >> 8) & 0xff) << 20) | ((block & 1023) << 10) | ((unsigned)ticket & 1023);
+}
+#endif
+template <int K, bool ONE, int U>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void tq_minibatch_kernel(
-    const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const tq_ksmogn_args k, const int64_t B) {
+    const tq_cosmos_args a, const tq_cosmos_args prev, const int has_prev, const tq_ksmogn_args k, const int64_t B,
+    const int tail_last) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int s_ticket, s_ok;
+  __shared__ int s_ticket, s_ok, s_role;
   __shared__ float s_part[4][TQ_ROWS_MAXCOL];
   const int tid = threadIdx.x;
 #ifdef TQ_MB_STAMPS
-#define TQ_STAMP(n) if (tid == 0 && blockIdx.x == TQ_MB_STAMPS) ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();
-#define TQ_TAIL_STAMP(n) if (tid == 0) ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();
+  uint64_t tq_tloc[8];  // (every workgroup keeps its own stamps too: maxima over the grid at stamp 5, words 16..21)
+#define TQ_STAMP(n)                                                                   \
+  if (tid == 0) {                                                                     \
+    tq_tloc[n] = __builtin_amdgcn_s_memrealtime();                                    \
+    if (blockIdx.x == TQ_MB_STAMPS) ((uint64_t*)(a.sync + 4))[n] = tq_tloc[n];        \
+    if (n == 5) {                                                                     \
+      unsigned long long* mx = (unsigned long long*)(a.sync + 4) + 16;                \
+      atomicMax(mx + 0, (unsigned long long)(tq_tloc[1] - tq_tloc[0]));               \
+      atomicMax(mx + 1, (unsigned long long)(tq_tloc[2] - tq_tloc[1]));               \
+      atomicMax(mx + 2, (unsigned long long)(tq_tloc[3] - tq_tloc[2]));               \
+      atomicMax(mx + 3, (unsigned long long)(tq_tloc[4] - tq_tloc[3]));               \
+      atomicMax(mx + 4, (unsigned long long)(tq_tloc[5] - tq_tloc[4]));               \
+      atomicMax(mx + 5, (unsigned long long)(tq_tloc[5] - tq_tloc[0]));               \
+      atomicMax(mx + 6, ((unsigned long long)(tq_tloc[5] - tq_tloc[0]) << 32) | tq_where(blockIdx.x, s_ticket)); \
+    }                                                                                 \
+  }
+#define TQ_TAIL_STAMP(n)                                                                     \
+  if (tid == 0) {                                                                            \
+    ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();                         \
+    if (n == 8) ((uint64_t*)(a.sync + 4))[23] = tq_where(blockIdx.x, s_ticket);              \
+  }
 #else
 #define TQ_STAMP(n)
 #define TQ_TAIL_STAMP(n)
@@ -1075,6 +1122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     if (done == (int)gridDim.x - 1) {
       __hip_atomic_store(&a.sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&a.sync[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.sync[TQ_SYNC_CLAIM], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   if (ticket >= (int)gridDim.x) {
@@ -1086,14 +1134,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     }
     return;
   }
-  if (ticket == 0) {  // the extra workgroup of the grid: owns no units
+  // Who runs the tail.  Ticket 0 by default: that workgroup is resident whatever else the chip is doing, and it waits for
+  // nobody.  With `tail_last` (a grid of 256 k + 1 workgroups: every CU hosts k of them and ONE hosts k + 1) the LAST block
+  // of the grid -- dispatched last, so the one that doubles up on a CU -- claims the tail if it gets there within a few
+  // microseconds: the tail is short, and the workgroup it shares the CU with keeps its SIMDs to itself for the long
+  // likelihood phase (two workers on one CU take twice as long there and ARE the critical path of the launch).  The
+  // ticket-0 workgroup then takes over the units of the claimer.  It polls the claim for a bounded time only and
+  // claims the tail itself when nothing arrives: progress never depends on a workgroup that is not resident yet.
+  int work = ticket - 1;
+  bool is_tail = ticket == 0;
+  if (tail_last) {
+    if (tid == 0) {
+      int role = ticket == 0 ? -1 : ticket - 1;  // -1: the tail
+      if (blockIdx.x == gridDim.x - 1 && ticket != 0) {
+        int expected = 0;
+        if (__hip_atomic_compare_exchange_strong(&a.sync[TQ_SYNC_CLAIM], &expected, ticket + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+          role = -1;
+      } else if (ticket == 0 && blockIdx.x != gridDim.x - 1) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        int c;
+        while ((c = __hip_atomic_load(&a.sync[TQ_SYNC_CLAIM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 &&
+               __builtin_amdgcn_s_memrealtime() - t0 < 600ull)  // 6 us of the 100 MHz clock
+          __builtin_amdgcn_s_sleep(2);
+        if (c == 0 && !__hip_atomic_compare_exchange_strong(&a.sync[TQ_SYNC_CLAIM], &c, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT)) {
+          // (lost the race at the last moment: c now holds the claimer's ticket + 1)
+        }
+        if (c != 0) role = c - 2;  // the units the claimer would have had
+      }
+      s_role = role;
+    }
+    __syncthreads();
+    work = s_role;
+    is_tail = work < 0;
+  }
+  if (is_tail) {  // the extra workgroup of the grid: owns no units
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
     TQ_TAIL_STAMP(8)
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
       if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
-      else if (has_prev == 4) tq_rows_reduce_globals_body<16>(prev, s_w, s_e);
+      else if (has_prev == 4 || has_prev == 7) tq_rows_reduce_globals_body<16>(prev, s_w, s_e, has_prev == 7 ? 20 : 16);
       else tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
       __syncthreads();
       TQ_TAIL_STAMP(9)
@@ -1124,9 +1207,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     if (tid == 0) count_out();
     return;
   }
-  // ---- phase 1: catch-up + site draws of this workgroup's 16 units (work index = ticket - 1) ----
-  const int64_t wblk = ticket - 1;
-  const int64_t u0 = wblk * TQ_UNITS_PER_BLOCK;
+  // ---- phase 1: catch-up + site draws of this workgroup's U units (work index = ticket - 1) ----
+  const int64_t wblk = work;
+  const int64_t u0 = wblk * U;
+  const int64_t u_end = u0 + U < B ? u0 + U : B;
   constexpr int NL = TQ_NLOCAL(K), NS = 1 + 4 * K;
   TQ_STAMP(7)
   if (a.last_step) {
@@ -1136,20 +1220,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     const int T0 = s1 - (TQ_BIAS_TABLE_STEPS - 1) > 1 ? s1 - (TQ_BIAS_TABLE_STEPS - 1) : 1;
     // the chain of dependent loads of every element of this thread (subsample index -> unit -> last step -> values) is
     // issued first and overlaps with the table build
-    constexpr int NPASS = (NL * TQ_UNITS_PER_BLOCK + 255) / 256;
+    constexpr int NPASS = (NL * U + 255) / 256;
     int64_t ej[NPASS];
     int es0[NPASS];
     float ep[NPASS], em[NPASS], ev[NPASS];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       const int e = tid + 256 * q;
-      const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
+      const int64_t i = u0 + (e % U);
       ej[q] = -1;
       es0[q] = s1 + 1;
       ep[q] = em[q] = ev[q] = 0.0f;
-      if (e < NL * TQ_UNITS_PER_BLOCK && i < B) {
+      if (e < NL * U && i < B) {
         const int64_t u = tq_decode_unit(a, i).u;
-        ej[q] = (int64_t)(e >> 4) * tq_num_units(a) + u;
+        ej[q] = (int64_t)(e / U) * tq_num_units(a) + u;
         es0[q] = a.last_step[u] + 1;
         ep[q] = a.params[ej[q]];
         em[q] = a.exp_avg[ej[q]];
@@ -1175,18 +1259,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     __syncthreads();
   }
   TQ_STAMP(1)
-  if constexpr (K <= 3) {
+  if constexpr (K <= 3 && (K + 1) * U <= 64) {
     // one KIND of site per wave -- wave 0 the K+1 Gamma sites (background, heights), waves 1..3 the width / x / y sites --
     // so that no wave runs the Gamma code and then the Beta code (with its regimes) for different lanes
     const int w = tid >> 6, l = tid & 63;
-    const int nl = (w == 0 ? K + 1 : K) * TQ_UNITS_PER_BLOCK;
-    const int site = (w == 0 ? 0 : K + 1 + (w - 1) * K) + (l >> 4);
-    const int64_t i = u0 + (l & (TQ_UNITS_PER_BLOCK - 1));
+    const int nl = (w == 0 ? K + 1 : K) * U;
+    const int site = (w == 0 ? 0 : K + 1 + (w - 1) * K) + (l / U);
+    const int64_t i = u0 + (l % U);
     if (l < nl && i < B) tq_body_site(a, site, i);
   } else {
-    for (int e = tid; e < NS * TQ_UNITS_PER_BLOCK; e += 256) {
-      const int64_t i = u0 + (e & (TQ_UNITS_PER_BLOCK - 1));
-      if (i < B) tq_body_site(a, e >> 4, i);
+    for (int e = tid; e < NS * U; e += 256) {
+      const int64_t i = u0 + (e % U);
+      if (i < B) tq_body_site(a, e / U, i);
     }
   }
   __syncthreads();
@@ -1221,8 +1305,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     return;
   }
   TQ_STAMP(3)
-  // ---- phase 2: likelihood of the 16 units (reads the draws of phase 1 and the gain) ----
-  tq_ksmogn_tile16<K, ONE, true>(k, B, wblk, smem);
+  // ---- phase 2: likelihood of the U units (reads the draws of phase 1 and the gain): sixteen of them with 16 lanes each,
+  // and of U = 20 the last four with a wave each (tq_mb_upr: why 20)
+  tq_ksmogn_tile_at<K, ONE, true, 16, 16, false>(k, B, u0, u_end, smem);
+  if constexpr (U > 16) {
+    static_assert(U == 20, "16 units at 16 lanes + 4 at 64");
+    tq_ksmogn_tile_at<K, ONE, true, 64, 16, true>(k, B, u0 + 16, u_end, smem);
+  }
   __syncthreads();
   TQ_STAMP(4)
   // ---- phase 3: per-unit terms + Adam, one lane per unit; row of partial sums ----
@@ -1232,8 +1321,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   for (int j = 0; j < TQ_MAX_NGSUM; ++j) part[j] = 0.0f;
 #pragma unroll
   for (int j = 0; j < TQ_ROWS_GCOL; ++j) aoi[j] = 0.0f;
-  const int64_t i = u0 + (tid >> 4);
-  if ((tid & 15) == 0 && i < B) {
+  // (units 16..19 of U = 20: the second lane of the first four 16-lane groups)
+  const int64_t i = u0 + (tid >> 4) + 16 * (tid & 15);
+  if ((tid & 15) < (U + 15) / 16 && i < u_end) {
     float aoi2[2];
     tq_body_unit<K>(a, i, part, aoi2);
     const uint32_t FC = (uint32_t)(a.fb * a.C);
@@ -1558,7 +1648,7 @@ static int launch_reduce_globals(const tq_cosmos_args* a, hipStream_t st) {
   }
   // no all-reduce on this path: sums, (per-AOI sites,) global sites and the total ELBO finish in one launch
   if (a->tail_kind == TQ_TAIL_ROWS16 || tq_rows_layout(*a)) {
-    hipLaunchKernelGGL(tq_rows_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a, a->tail_kind == TQ_TAIL_ROWS16 ? 16 : TQ_UNIT_BLOCK);
+    hipLaunchKernelGGL(tq_rows_reduce_globals_kernel, dim3(1), dim3(256), 0, st, *a, a->tail_kind == TQ_TAIL_ROWS16 ? tq_mb_upr(*a) : TQ_UNIT_BLOCK);
     return check_launch("tq_rows_reduce_globals_kernel");
   }
   const int64_t B = tq_batch_units(*a);
@@ -1618,7 +1708,7 @@ extern "C" int tq_cosmos_step_overlapped(const tq_cosmos_args* a, const tq_cosmo
     return TQ_ERR_ARG;
   }
   const int64_t B = tq_batch_units(*a);
-  if (prev && tq_prev_code(*prev) == 4) {
+  if (prev && prev->tail_kind == TQ_TAIL_ROWS16) {
     // (a pending single-launch minibatch step: its rows-of-16 tail is not carried by the sampling launch, whose register
     // allocation every extra tail variant burdens)
     if (int rc = tq_cosmos_tail(prev, stream)) return rc;
@@ -1670,8 +1760,11 @@ extern "C" int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos
   const int64_t B = tq_batch_units(*a);
   const tq_ksmogn_args k = cosmos_ksmogn_args(a);
   const bool one = a->O == 1 && a->pixstats;
-  // one workgroup per 16 units + the one that runs the tail and the global draws
-  const dim3 grid((unsigned)((B + TQ_UNITS_PER_BLOCK - 1) / TQ_UNITS_PER_BLOCK) + 1), block(256);
+  // one workgroup per 16 (or 20: tq_mb_upr) units + the one that runs the tail and the global draws
+  const int upr = tq_mb_upr(*a);
+  const dim3 grid((unsigned)((B + upr - 1) / upr) + 1), block(256);
+  const char* tl = getenv("TAPQIR_AMD_MB_TAIL_LAST");
+  const int tail_last = !(tl && tl[0] == '0') && grid.x > 1 && (grid.x - 1) % 256 == 0 && grid.x <= 513;  // (<= 2 workgroups per CU: all resident)
   size_t lds = sizeof(float) * tq_tile16_lds_floats(a->P, a->K, a->O);
   if (a->next_ndx || a->next_fdx) {
     if ((a->next_ndx && a->Nt > TQ_SUBSAMPLE_MAX) || (a->next_fdx && a->F > TQ_SUBSAMPLE_MAX)) {
@@ -1684,9 +1777,14 @@ extern "C" int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos
   const int code = prev ? tq_prev_code(*prev) : 0;
   const tq_cosmos_args& pv = prev ? *prev : *a;
   hipStream_t st = (hipStream_t)stream;
-#define TQ_MB_LAUNCH(KK)                                                                                         \
-  if (one) hipLaunchKernelGGL((tq_minibatch_kernel<KK, true>), grid, block, lds, st, *a, pv, code, k, B);       \
-  else hipLaunchKernelGGL((tq_minibatch_kernel<KK, false>), grid, block, lds, st, *a, pv, code, k, B);
+#define TQ_MB_LAUNCH(KK)                                                                                                 \
+  if (upr == 20) {                                                                                                       \
+    if (one) hipLaunchKernelGGL((tq_minibatch_kernel<KK, true, 20>), grid, block, lds, st, *a, pv, code, k, B, tail_last);         \
+    else hipLaunchKernelGGL((tq_minibatch_kernel<KK, false, 20>), grid, block, lds, st, *a, pv, code, k, B, tail_last);            \
+  } else {                                                                                                               \
+    if (one) hipLaunchKernelGGL((tq_minibatch_kernel<KK, true, 16>), grid, block, lds, st, *a, pv, code, k, B, tail_last);         \
+    else hipLaunchKernelGGL((tq_minibatch_kernel<KK, false, 16>), grid, block, lds, st, *a, pv, code, k, B, tail_last);            \
+  }
   switch (a->K) {
     case 1: TQ_MB_LAUNCH(1) break;
     case 2: TQ_MB_LAUNCH(2) break;

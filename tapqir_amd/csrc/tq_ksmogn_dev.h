@@ -300,24 +300,31 @@ __host__ __device__ inline size_t tq_tile16_lds_floats(int P, int K, int O = 1, 
 // LANES lanes per unit (16: sixteen units per workgroup of 256 threads; 64: four units, a wave each -- the offset-histogram
 // form of gathered batches, whose offset loop is long enough to want every wave slot of the chip: a 10 x 512 minibatch is
 // 5120 units = 1280 waves at 16 lanes per unit, 5120 at 64).
-template <int K, bool ONE_OFFSET, bool BWD, int LANES = TQ_LANES_PER_UNIT>
-__device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const int64_t B, const int64_t blk, float* smem) {
+// tq_ksmogn_tile_at: the TQ_BLOCK / LANES units [i0, i0 + TQ_BLOCK / LANES) of the batch below i_end; LDS_UNITS = unit slots of
+// the LDS layout (tiles, factor tables, then the offset table): a caller that runs a 16-lane pass and then a 64-lane pass over
+// the same LDS (the minibatch step with 20 units per workgroup) keeps the layout of 16 slots for both -- the four units of
+// the second pass use slots 0, 4, 8, 12, which the SAME wave owned in the first pass, so no workgroup barrier separates the
+// passes -- and the offset table built by the first pass (TAB_READY).
+template <int K, bool ONE_OFFSET, bool BWD, int LANES, int LDS_UNITS, bool TAB_READY>
+__device__ __forceinline__ void tq_ksmogn_tile_at(const tq_ksmogn_args& a, const int64_t B, const int64_t i0, const int64_t i_end, float* smem) {
   constexpr int M = 1 << K;
   constexpr int UNITS = TQ_BLOCK / LANES;
+  static_assert(LDS_UNITS % UNITS == 0, "slots of a pass are a stride of the layout's");
 
   const int tid = threadIdx.x;
   const int grp = tid / LANES;
   const int r = tid % LANES;
-  const int64_t i_raw = blk * UNITS + grp;
-  const bool live = i_raw < B;
+  const int64_t i_raw = i0 + grp;
+  const bool live = i_raw < i_end;
   const int64_t i = live ? i_raw : (B - 1);  // dead groups shadow the last unit, stores masked
 
   // ---- decode minibatch position -> dataset unit -------------------------------------------
   const int P = a.P;
   const int npix = P * P;
   const int stride = tq_tile_stride(npix);
-  float* s_tile = smem + grp * stride;
-  float* s_fac = smem + UNITS * stride + grp * (2 * K * TQ_MAX_P);
+  const int slot = grp * (LDS_UNITS / UNITS);
+  float* s_tile = smem + slot * stride;
+  float* s_fac = smem + LDS_UNITS * stride + slot * (2 * K * TQ_MAX_P);
   // (B < 2^31 is checked on the host; 32-bit arithmetic, and no division at all for a contiguous batch)
   const uint32_t iu = (uint32_t)i;
   int n;
@@ -373,8 +380,8 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
 
   // offset histogram: extrema and per-offset constants once per workgroup (every thread of the workgroup is here)
   float* s_off = nullptr;
-  if (!ONE_OFFSET && a.O <= TQ_OFFTAB_MAX) {
-    s_off = smem + UNITS * (stride + 2 * K * TQ_MAX_P);
+  if (!ONE_OFFSET && a.O <= TQ_OFFTAB_MAX) s_off = smem + LDS_UNITS * (stride + 2 * K * TQ_MAX_P);
+  if (!ONE_OFFSET && a.O <= TQ_OFFTAB_MAX && !TAB_READY) {
     if (tid < 64) {  // min / max are exact: the values of tq_offset_info
       float lo = INFINITY, hi = -INFINITY, lw = -INFINITY, lwn = INFINITY;
       for (int o = tid; o < a.O; o += 64) {
@@ -455,5 +462,11 @@ __device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const 
     }
     tq_pixel_store<K, ONE_OFFSET, BWD>(a, B, i, A, W, b, rg, hk, wk, cxs, cys, (float)npix, S_v, bad);
   }
+}
+
+template <int K, bool ONE_OFFSET, bool BWD, int LANES = TQ_LANES_PER_UNIT>
+__device__ __forceinline__ void tq_ksmogn_tile16(const tq_ksmogn_args& a, const int64_t B, const int64_t blk, float* smem) {
+  constexpr int UNITS = TQ_BLOCK / LANES;
+  tq_ksmogn_tile_at<K, ONE_OFFSET, BWD, LANES, UNITS, false>(a, B, blk * UNITS, B, smem);
 }
 

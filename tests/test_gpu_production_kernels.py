@@ -19,6 +19,8 @@ import torch
 from helpers import (GIVEN_STAGES, CosmosEngine, fp32_latents, make_dataset, make_oracle, oracle_grads, oracle_to_engine,
                      put_latents, read_engine_latents, rel_err)
 
+from tapqir_amd.models.cosmos import initial_values
+
 pytestmark = pytest.mark.gpu
 
 ELBO_RTOL, PARAM_ATOL = 2e-5, 1e-4
@@ -115,6 +117,58 @@ def test_single_launch_minibatch_kernel_against_oracle(name, K, dkw, nb, fb):
     replay(eng, o, dkw["N"], dkw["F"], nb=nb, fb=fb)
     assert len(calls) == 3
     assert (eng.O == 1) == (dkw.get("offsets") is None)
+
+
+# The same launch with 20 units per workgroup (16 at 16 lanes + 4 with a wave each), which the library picks when that takes
+# fewer rounds of pixel iterations on 256 CUs -- the default 10 x 512 minibatch -- forced here on batches the oracle can
+# replay: 3 x 21 = 63 units = three workgroups of 20 and one of 3 (the wave-per-unit pass of the last one all dead lanes).
+MB_U20_CASES = [
+    ("K2_hist", 2, dict(N=5, F=24, offsets="hist"), 3, 21),
+    ("K2_one_offset", 2, dict(N=5, F=24), 3, 21),
+    ("K2_wide_partly_masked_offsets", 2, dict(N=5, F=24, offsets="wide"), 3, 23),
+    ("K1_hist", 1, dict(N=5, F=24, offsets="hist"), 3, 21),
+    ("K3_hist", 3, dict(N=5, F=24, offsets="hist"), 2, 24),  # (K + 1) U > 64: the site draws take the generic loop
+    ("K4_one_offset", 4, dict(N=5, F=24), 2, 20),
+    ("K2_two_channels", 2, dict(N=4, F=20, C=2), 2, 11),
+    ("K2_P20", 2, dict(N=4, F=24, P=20), 2, 22),
+]
+
+
+@pytest.mark.parametrize("name,K,dkw,nb,fb", MB_U20_CASES, ids=[c[0] for c in MB_U20_CASES])
+def test_single_launch_minibatch_kernel_20_units_per_workgroup(name, K, dkw, nb, fb, monkeypatch):
+    monkeypatch.setenv("TAPQIR_AMD_MB_UNITS", "20")
+    d, o, eng = setup(K, dkw)
+    assert eng.fused_minibatch and eng.lazy_adam and fb * eng.C >= 20
+    replay(eng, o, dkw["N"], dkw["F"], nb=nb, fb=fb)
+    eng.join()  # (the pending tail is sized by the same environment variable)
+
+
+def test_minibatch_tail_claimed_by_the_last_block_changes_nothing(monkeypatch):
+    """The default 10 x 512 minibatch = 256 workgroups of 20 units + 1: the block dispatched last claims the tail and the
+    ticket-0 workgroup takes over its units (tq_minibatch_kernel, `tail_last`).  Which workgroup runs which role must not
+    show in the results: bit-identical parameters with the claim on and off; and the 20-unit split against the 16-unit one
+    to rounding (the wave-per-unit pass adds a unit's pixels in another order)."""
+    d = make_dataset(N=12, F=600, K=2, offsets="hist")
+
+    def run(units, claim):
+        monkeypatch.setenv("TAPQIR_AMD_MB_UNITS", units)
+        monkeypatch.setenv("TAPQIR_AMD_MB_TAIL_LAST", claim)
+        eng = CosmosEngine(d, K=2, device="cuda:0", seed=3)
+        eng.layout.set_constrained(eng.params, initial_values(eng, d))
+        g = torch.Generator().manual_seed(1)
+        for _ in range(12):
+            eng.step(torch.randperm(12, generator=g)[:10], torch.randperm(600, generator=g)[:512])
+        eng.join()
+        torch.cuda.synchronize()
+        return eng.params.clone(), float(eng.elbo_out[0])
+
+    p_on, e_on = run("20", "1")
+    p_off, e_off = run("20", "0")
+    assert bool(torch.isfinite(p_on).all())
+    assert torch.equal(p_on, p_off) and e_on == e_off
+    p16, e16 = run("16", "1")
+    assert abs(e16 - e_on) <= 1e-5 * abs(e16)
+    assert float((p16 - p_on).abs().max()) < 2e-4  # 12 Adam steps of lr = 0.005
 
 
 # ---- (c) BASELINE config c1 at full size: K = 1, 50 AOIs x 100 frames, the whole batch against the dense oracle -----------
