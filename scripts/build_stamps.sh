@@ -6,11 +6,11 @@ set -e
 cd "$(dirname "$0")/.."
 python -m tapqir_amd.build >/dev/null
 for blk in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -DTQ_MB_STAMPS=$blk -c tapqir_amd/csrc/tq_cosmos.hip \
-    -o tapqir_amd/build/tq_cosmos_stamps_$blk.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -DTQ_MB_STAMPS=$blk -DTQ_MB_STAMPS_SITES=${SITES:-0} -c tapqir_amd/csrc/tq_cosmos.hip \
+    -o tapqir_amd/build/tq_cosmos_stamps_$blk${SITES:+_s$SITES}.o &
 done
 wait
 for blk in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tapqir_amd/libtapqir_hip_stamps_$blk.so tapqir_amd/build/tq_ksmogn.o \
-    tapqir_amd/build/tq_xtalk.o tapqir_amd/build/tq_cosmos_stamps_$blk.o tapqir_amd/build/tq_glimpse.o tapqir_amd/build/tq_aux.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tapqir_amd/libtapqir_hip_stamps_$blk${SITES:+_s$SITES}.so tapqir_amd/build/tq_ksmogn.o \
+    tapqir_amd/build/tq_xtalk.o tapqir_amd/build/tq_cosmos_stamps_$blk${SITES:+_s$SITES}.o tapqir_amd/build/tq_glimpse.o tapqir_amd/build/tq_aux.o
 done

@@ -69,9 +69,13 @@ TQ_HD void tq_body_sample_globals(const tq_cosmos_args& a, int s) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TQ_LOAD_STREAM(p) __builtin_nontemporal_load(p)
 #define TQ_STORE_STREAM(v, p) __builtin_nontemporal_store(v, p)
+// a value another workgroup of the SAME launch has published (release at device scope + flag): a device-scope load goes past
+// the CU's vector cache and a stale line in this XCD's L2 -- without the acquire fence that invalidates both for everybody
+#define TQ_LOAD_COHERENT(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define TQ_LOAD_STREAM(p) (*(p))
 #define TQ_STORE_STREAM(v, p) (*(p) = (v))
+#define TQ_LOAD_COHERENT(p) (*(p))
 #endif
 
 // ---- local guide sites: work item (site, i), site in [0, 1+4K): b, h[k], w[k], x[k], y[k]; row t = site * B + i ---
@@ -175,13 +179,16 @@ TQ_HD void tq_adam_apply_given(const tq_cosmos_args& a, int64_t j, float p, floa
 // pixv != nullptr: the pixel kernel's results for this unit (the rows of a.pix, in row order) are taken from there (the
 // fused pixel + per-unit kernel hands them over in registers).
 // STREAM: the Adam moments are read and written with non-temporal accesses (full-batch steps: touched once per step).
-template <int K, bool LATE_MOMENTS = false, bool STREAM = false>
-TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* aoi2 = nullptr, const float* pixv = nullptr) {
+// COHERENT_AOI / Gp: the single-launch minibatch step, where the per-AOI parameters and the global tables are written by
+// the tail workgroup of the same launch (tq_minibatch_kernel): device-scope loads, the caller's copy of the tables.
+template <int K, bool LATE_MOMENTS = false, bool STREAM = false, bool COHERENT_AOI = false>
+TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* aoi2 = nullptr, const float* pixv = nullptr,
+                        const TqGlobals* Gp = nullptr) {
   constexpr int M = 1 << K;
   constexpr int NL = TQ_NLOCAL(K);
   const int64_t B = tq_batch_units(a), U = tq_num_units(a);
   const TqUnitIdx ix = tq_decode_unit(a, i);
-  const TqGlobals& G = *(const TqGlobals*)a.globals;
+  const TqGlobals& G = Gp ? *Gp : *(const TqGlobals*)a.globals;
   TqSiteConsts C;
   C.H = 0.5f * (a.P + 1);
   C.eps = a.eps;
@@ -194,8 +201,8 @@ TQ_HD void tq_body_unit(const tq_cosmos_args& a, int64_t i, float* part, float* 
   for (int r = 0; r < NL; ++r) in.u[r] = a.params[(int64_t)r * U + ix.u];
   const int64_t ab = tq_aoi_base(a);
   const int64_t nc = (int64_t)ix.n * a.C + ix.c;
-  in.u_bml = a.params[ab + nc];
-  in.u_bsl = a.params[ab + (int64_t)a.Nt * a.C + nc];
+  in.u_bml = COHERENT_AOI ? TQ_LOAD_COHERENT(&a.params[ab + nc]) : a.params[ab + nc];
+  in.u_bsl = COHERENT_AOI ? TQ_LOAD_COHERENT(&a.params[ab + (int64_t)a.Nt * a.C + nc]) : a.params[ab + (int64_t)a.Nt * a.C + nc];
   in.b = a.lat[i];
 #pragma unroll
   for (int k = 0; k < K; ++k) {

@@ -339,7 +339,12 @@ __device__ __forceinline__ void tq_globals_from_gsum_body(const tq_cosmos_args& 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ns = tq_num_gsites(a);
   if (lane == 0)
-    for (int s = wave; s < ns; s += 4) s_e[s] = tq_body_globals_grad(a, s);
+    for (int s = wave; s < ns; s += 4) {
+      s_e[s] = tq_body_globals_grad(a, s);
+#if defined(TQ_MB_STAMPS) && TQ_MB_STAMPS_SITES == 1
+      if (a.sync && s < 4) ((uint64_t*)(a.sync + 4))[24 + s] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
   __syncthreads();
   if (threadIdx.x == 0) {
     double eg = 0.0;
@@ -378,11 +383,11 @@ __device__ __forceinline__ void tq_reduce_sums_body(const tq_cosmos_args& a, con
 
 // sums, then the global sites and the total ELBO (single-GPU steps: no all-reduce in between)
 __device__ __forceinline__ void tq_reduce_globals_body(const tq_cosmos_args& a, const int64_t nblk, const int64_t B,
-                                                       double (*s_w)[TQ_MAX_NGSUM], double* s_e) {
+                                                       double (*s_w)[TQ_MAX_NGSUM], double* s_e, const bool with_globals = true) {
   tq_reduce_sums_body(a, nblk, B, s_w);
   __threadfence_block();
   __syncthreads();
-  tq_globals_from_gsum_body(a, s_e);
+  if (with_globals) tq_globals_from_gsum_body(a, s_e);
 }
 
 // ---- finish the cross-unit sums in fp64 (single workgroup; sharded runs all-reduce gsum after it) ------------------
@@ -455,6 +460,9 @@ static int tq_mb_upr(const tq_cosmos_args& a) {
   const int forced = e ? atoi(e) : 0;
   if ((int64_t)a.fb * a.C < 20 || forced == 16) return 16;
   if (forced == 20) return 20;
+  // (single offset: the likelihood phase is 8 us of a 40 us workgroup and the second pass adds latency -- 55.5 against
+  // 53.0 us per step measured with 20)
+  if (a.O < 8) return 16;
   const int64_t B = tq_batch_units(a);
   const int64_t r16 = ((B + 15) / 16 + 255) / 256, r20 = ((B + 19) / 20 + 255) / 256;
   return 17 * r20 < 13 * r16 ? 20 : 16;
@@ -537,6 +545,8 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
 #define TQ_GRP_UNITS 4096
 #define TQ_GRP_AOIS (TQ_GRP_UNITS / TQ_UNIT_BLOCK + 1)   /* AOIs a group can touch (F * C >= TQ_UNIT_BLOCK) */
 #define TQ_GGROW (2 * 16 + TQ_GRP_AOIS * 2 * TQ_MAXQ)    /* floats of a group row: 16 doubles, then 2 * TQ_MAXQ floats per AOI */
+#define TQ_SYNC_GAIN 62                                  /* the gain of a minibatch launch (float bits), published with the first flag */
+#define TQ_SYNC_FLAG2 61                                 /* second flag of a minibatch launch: the global draws after the gain */
 #define TQ_SYNC_CLAIM 60                                 /* word that names the workgroup running the tail of a minibatch launch (tail_last) */
 #define TQ_SYNC_GROUPS 40                                /* word of tq_cosmos_args.sync that counts the finished groups */
 __host__ __device__ __forceinline__ int64_t tq_grp_count(int64_t B) { return (B + TQ_GRP_UNITS - 1) / TQ_GRP_UNITS; }
@@ -682,7 +692,7 @@ __device__ __forceinline__ void tq_rows_column_sums(const tq_cosmos_args& a, int
 // = 16 or 20 units: the host's tq_mb_upr)
 template <int UPR_T>
 __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args& a, double (*s_w)[TQ_MAX_NGSUM], double* s_e,
-                                                            const int mb_upr = 16) {
+                                                            const int mb_upr = 16, const bool with_globals = true) {
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
   const int64_t B = tq_batch_units(a);
   const uint32_t UPR = UPR_T == 16 ? (uint32_t)mb_upr : (uint32_t)tq_rows_upr(a);  // (one instance serves rows of 64 and of 256)
@@ -778,7 +788,7 @@ __device__ __forceinline__ void tq_rows_reduce_globals_body(const tq_cosmos_args
 #ifdef TQ_MB_STAMPS
   if (threadIdx.x == 0 && a.sync) ((uint64_t*)(a.sync + 4))[12] = __builtin_amdgcn_s_memrealtime();
 #endif
-  tq_globals_from_gsum_body(a, s_e);
+  if (with_globals) tq_globals_from_gsum_body(a, s_e);
 }
 
 // Sums of a step from the group rows that other workgroups publish (ONE workgroup of 256 threads): WAIT: polls the counter of
@@ -1173,29 +1183,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     __shared__ double s_w[4][TQ_MAX_NGSUM];
     __shared__ double s_e[TQ_NGSITES(TQ_MAXQ)];
     TQ_TAIL_STAMP(8)
+    // The workers need the GAIN of this step before their likelihood phase and the other global draws (tables of pi, lamda,
+    // proximity) only in the per-unit phase after it: the gain's chain -- gradient of its site, Adam of its two
+    // parameters, the draw -- runs on wave 0 by itself and is published first (sync[1]); the other sites' gradients
+    // (7-8 us each against 3.5) run beside it on waves 1..3, and their Adam and draws follow under a second flag
+    // (sync[TQ_SYNC_FLAG2]) that is long set when a worker gets to it.
+    const int lane = tid & 63, wave = tid >> 6;
     if (has_prev) {
       const int64_t Bp = tq_batch_units(prev);
-      if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e);
-      else if (has_prev == 4 || has_prev == 7) tq_rows_reduce_globals_body<16>(prev, s_w, s_e, has_prev == 7 ? 20 : 16);
-      else tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e);
-      __syncthreads();
-      TQ_TAIL_STAMP(9)
-      const int64_t total = tq_num_params(prev);
-      for (int64_t j = tq_aoi_base(prev) + tid; j < total; j += 256) tq_body_adam(prev, j);
+      if (has_prev == 3) tq_rows_reduce_globals_body<TQ_UNIT_BLOCK>(prev, s_w, s_e, 16, false);
+      else if (has_prev == 4 || has_prev == 7) tq_rows_reduce_globals_body<16>(prev, s_w, s_e, has_prev == 7 ? 20 : 16, false);
+      else tq_reduce_globals_body(prev, (Bp + TQ_UNIT_BLOCK - 1) / TQ_UNIT_BLOCK, Bp, s_w, s_e, false);
+      // (the bodies end with gsum stored, a workgroup-scope fence and a barrier)
+      if (lane == 0) {
+        const int nsp = tq_num_gsites(prev);
+        if (wave == 0) {
+          s_e[0] = tq_body_globals_grad(prev, 0);
+          const int64_t gb = tq_global_base(prev);  // [0] gain_loc [1] gain_beta (tq_globals.h)
+          tq_body_adam(prev, gb);
+          tq_body_adam(prev, gb + 1);
+        } else {
+          for (int sg = wave; sg < nsp; sg += 3) s_e[sg] = tq_body_globals_grad(prev, sg);
+        }
+      }
+    }
+    if (wave == 0) {
+      if (lane == 0) {
+        tq_body_sample_globals(a, 0);
+        // publish: the gain once more in a sync word (what the workers read: wait_flag), then the storing lane drains,
+        // releases at device scope and sets the flag
+        __hip_atomic_store(&a.sync[TQ_SYNC_GAIN], __float_as_int(((const TqGlobals*)a.globals)->gain), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&a.sync[1], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    TQ_TAIL_STAMP(9)
+    if (has_prev) {
+      if (tid == 0) {  // total ELBO of the previous step (as tq_globals_from_gsum_body)
+        const int nsp = tq_num_gsites(prev);
+        double eg = 0.0;
+        for (int j = 0; j < nsp; ++j) eg += s_e[j];
+        prev.elbo_out[0] = prev.gsum[TQ_GS_ELBO] + (double)prev.global_weight * eg;
+      }
+      const int64_t total = tq_num_params(prev), gb = tq_global_base(prev);
+      for (int64_t j = tq_aoi_base(prev) + tid; j < total; j += 256)
+        if (j != gb && j != gb + 1) tq_body_adam(prev, j);
       __threadfence_block();
       __syncthreads();
     }
     TQ_TAIL_STAMP(10)
     const int ns = tq_num_gsites(a);
-    if ((tid & 63) == 0)
-      for (int s = tid >> 6; s < ns; s += 4) tq_body_sample_globals(a, s);
-    // publish: every storing wave drains, workgroup barrier, one lane releases at device scope and sets the flag
+    if (lane == 0)
+      for (int sg = 1 + wave; sg < ns; sg += 4) tq_body_sample_globals(a, sg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&a.sync[1], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.sync[TQ_SYNC_FLAG2], flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     TQ_TAIL_STAMP(11)
     // the NEXT step's subsample (nobody waits for it: the next launch reads it)
@@ -1275,25 +1324,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   }
   __syncthreads();
   TQ_STAMP(2)
-  // ---- wait for the global draws of this step (bounded: ~2 s of the 100 MHz wall clock) ----
-  {
+  // ---- wait for the gain of this step (bounded: ~2 s of the 100 MHz wall clock) ----
+  __shared__ float s_gain;
+  auto wait_flag = [&](int word) {
     if (tid == 0) {
       const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
       int ok = 1;
-      while (__hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flag_value) {
+      while (__hip_atomic_load(&a.sync[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flag_value) {
         __builtin_amdgcn_s_sleep(16);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
           ok = 0;
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // No acquire fence: at device scope it invalidates the CU's vector cache AND this XCD's L2 for every workgroup on
+      // them.  What the tail workgroup publishes is read so that no stale copy can answer instead:
+      //   the gain        from a sync word, with a device-scope load (here);
+      //   TqGlobals       with plain (scalar) loads in the per-unit phase, after the second flag: no workgroup touches the
+      //                   struct's cache lines earlier in the launch (the gain comes from the sync word for that reason), and
+      //                   a launch starts with clean caches;
+      //   per-AOI params  with device-scope loads in tq_body_unit (their first line also holds the end of the last
+      //                   local-parameter row, which a replay may have read).
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ok && word == 1) s_gain = __int_as_float(__hip_atomic_load(&a.sync[TQ_SYNC_GAIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       s_ok = ok;
     }
-  }
-  __syncthreads();
-  if (!s_ok) {  // never observed: leave a visible trace (NaN loss) instead of reading half-written tables
+    __syncthreads();
+    return s_ok != 0;
+  };
+  auto step_lost = [&]() {  // never observed: leave a visible trace (NaN loss) instead of reading half-written tables
     if (tid == 0) {
       // The step is lost.  Its row of partial sums carries a NaN ELBO, so the tail of this step (run by the next launch or
       // by tq_cosmos_tail) reports a NaN loss whichever workgroup was late, and Model.run rolls back to its last
@@ -1302,17 +1361,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       a.elbo_out[0] = __builtin_nan("");
       count_out();  // still counted: the ticket counter is re-armed for the launches that follow
     }
+  };
+  if (!wait_flag(1)) {
+    step_lost();
     return;
   }
   TQ_STAMP(3)
   // ---- phase 2: likelihood of the U units (reads the draws of phase 1 and the gain): sixteen of them with 16 lanes each,
   // and of U = 20 the last four with a wave each (tq_mb_upr: why 20)
-  tq_ksmogn_tile_at<K, ONE, true, 16, 16, false>(k, B, u0, u_end, smem);
+  tq_ksmogn_args kw = k;
+  kw.gain = &s_gain;  // (the copy read at the flag)
+  tq_ksmogn_tile_at<K, ONE, true, 16, 16, false>(kw, B, u0, u_end, smem);
   if constexpr (U > 16) {
     static_assert(U == 20, "16 units at 16 lanes + 4 at 64");
-    tq_ksmogn_tile_at<K, ONE, true, 64, 16, true>(k, B, u0 + 16, u_end, smem);
+    tq_ksmogn_tile_at<K, ONE, true, 64, 16, true>(kw, B, u0 + 16, u_end, smem);
   }
   __syncthreads();
+  // ---- the other global draws (tables of the per-unit terms): set long ago, unless the tail workgroup started late ----
+  if (!wait_flag(TQ_SYNC_FLAG2)) {
+    step_lost();
+    return;
+  }
   TQ_STAMP(4)
   // ---- phase 3: per-unit terms + Adam, one lane per unit; row of partial sums ----
   const int nq = tq_num_gsum(a), ncol = TQ_ROWS_GCOL + nq;
@@ -1325,7 +1394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   const int64_t i = u0 + (tid >> 4) + 16 * (tid & 15);
   if ((tid & 15) < (U + 15) / 16 && i < u_end) {
     float aoi2[2];
-    tq_body_unit<K>(a, i, part, aoi2);
+    tq_body_unit<K, false, false, true>(a, i, part, aoi2);
     const uint32_t FC = (uint32_t)(a.fb * a.C);
     const int c = (int)((uint32_t)i % (uint32_t)a.C);
     const int slot = (uint32_t)i / FC == (uint32_t)u0 / FC ? 0 : 1;
