@@ -47,6 +47,10 @@ if os.environ.get("STAMPS"):
     print("slowest workgroup: %.1f us at %s;  tail workgroup at %s" % ((int(w[0]) >> 32) / 100.0, where(int(w[0]) & 0xffffffff), where(int(w[1]))))
     mx = eng._sync[4 + 32:4 + 44].cpu().view(torch.int64)
     print("maxima over the workgroups (us): catchup %.1f  sites %.1f  wait %.1f  pixel %.1f  unit %.1f  total %.1f" % tuple(int(v) / 100.0 for v in mx))
+    if os.environ.get("CATCHUP"):  # inside the catch-up phase of workgroup STAMPS, thread 0
+        sw = eng._sync[4 + 48:4 + 56].cpu().view(torch.int64)
+        print("catch-up (us since its start): table built %.1f, barrier %.1f, first replay pass %.1f, second %.1f" %
+              tuple((int(v) - int(st[7])) / 100.0 for v in sw))
     if os.environ.get("SITES"):  # -DTQ_MB_STAMPS_SITES=1: gradient of global site s done; =2: its draw done (us since the tail's start)
         sw = eng._sync[4 + 48:4 + 56].cpu().view(torch.int64)
         print("global sites (%s) done at" % ("gradient" if os.environ["SITES"] == "1" else "draw"),

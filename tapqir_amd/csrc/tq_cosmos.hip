@@ -1077,6 +1077,46 @@ __device__ __forceinline__ void tq_draw_subsample(uint64_t* buf, uint64_t seed, 
 #define TQ_SITE_SUBSAMPLE_N 0xA00u
 #define TQ_SITE_SUBSAMPLE_F 0xA01u
 
+// Lazy-Adam replay of ONE element by G neighbouring lanes (the last, thinly filled pass of the catch-up phase: 32 of 288
+// elements at K = 2, which cost the workgroup a second full pass of ~136 dependent steps on one wave).  With zero gradient
+// the increment of step s0 + k depends on (m0 beta1^k, v0 beta2^k) and the step's bias factors only, not on the parameter:
+// lane `part` starts from the moments after k0 = part * ceil(n / G) steps (closed form), adds up the increments of its own
+// steps, the G sums are added and the parameter moves once.  Against the step-by-step form the sum is rounded once instead
+// of at every step (a few ulp of the parameter) and no increment is dropped as negligible.  Steps older than the bias
+// table take the plain replay on the first lane.
+template <int G>
+__device__ __forceinline__ void tq_adam_replay_split(const tq_cosmos_args& a, int64_t j, int s0, int s1, const float* tab, int T0,
+                                                     float p, float m, float v, int part) {
+  const bool valid = j >= 0 && s0 <= s1;
+  const bool direct = valid && s0 < T0;
+  const int n = valid ? s1 - s0 + 1 : 0;
+  float dp = 0.0f;
+  if (valid && !direct) {
+    const int L = (n + G - 1) / G;
+    const int k0 = part * L;
+    const int k1 = k0 + L < n ? k0 + L : n;
+    if (k0 < k1) {
+      float mm = m * (float)tq_powi((double)a.beta1, k0), vv = v * (float)tq_powi((double)a.beta2, k0);
+      const float* t = tab + 2 * (s0 + k0 - T0);
+#pragma unroll 4
+      for (int k = k0; k < k1; ++k, t += 2) {
+        mm = a.beta1 * mm;
+        vv = a.beta2 * vv;
+        dp += t[0] * mm * TQ_FRCP(TQ_FSQRT(vv) * t[1] + a.adam_eps);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) dp += __shfl_xor(dp, o, 64);
+  if (direct) {
+    if (part == 0) tq_adam_replay_tab_given(a, j, s0, s1, tab, T0, p, m, v);
+  } else if (valid && part == 0) {
+    a.params[j] = p - dp;
+    a.exp_avg[j] = m * (float)tq_powi((double)a.beta1, n);
+    a.exp_avg_sq[j] = v * (float)tq_powi((double)a.beta2, n);
+  }
+}
+
 #ifdef TQ_MB_STAMPS
 // (diagnostic) where a workgroup runs: XCC (4 bits) | SE, SH, CU of HW_ID (8 bits) | block (10 bits) | ticket (10 bits)
 __device__ __forceinline__ unsigned long long tq_where(unsigned block, int ticket) {
@@ -1111,6 +1151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       atomicMax(mx + 6, ((unsigned long long)(tq_tloc[5] - tq_tloc[0]) << 32) | tq_where(blockIdx.x, s_ticket)); \
     }                                                                                 \
   }
+#define TQ_STAMP2(n) if (tid == 0 && blockIdx.x == TQ_MB_STAMPS) ((uint64_t*)(a.sync + 4))[24 + n] = __builtin_amdgcn_s_memrealtime();
 #define TQ_TAIL_STAMP(n)                                                                     \
   if (tid == 0) {                                                                            \
     ((uint64_t*)(a.sync + 4))[n] = __builtin_amdgcn_s_memrealtime();                         \
@@ -1118,6 +1159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   }
 #else
 #define TQ_STAMP(n)
+#define TQ_STAMP2(n)
 #define TQ_TAIL_STAMP(n)
 #endif
   TQ_STAMP(0)
@@ -1270,12 +1312,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     // the chain of dependent loads of every element of this thread (subsample index -> unit -> last step -> values) is
     // issued first and overlaps with the table build
     constexpr int NPASS = (NL * U + 255) / 256;
+    // a thin last pass is shared out: G lanes per element (tq_adam_replay_split)
+    constexpr int XLAST = NL * U - 256 * (NPASS - 1);
+    constexpr int G = NPASS == 1 ? 1 : (XLAST <= 32 ? 8 : (XLAST <= 64 ? 4 : (XLAST <= 128 ? 2 : 1)));
     int64_t ej[NPASS];
     int es0[NPASS];
     float ep[NPASS], em[NPASS], ev[NPASS];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
-      const int e = tid + 256 * q;
+      const bool split = G > 1 && q == NPASS - 1;
+      const int e = split ? 256 * q + tid / G : tid + 256 * q;
       const int64_t i = u0 + (e % U);
       ej[q] = -1;
       es0[q] = s1 + 1;
@@ -1301,10 +1347,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
         pw2 *= b2_256;
       }
     }
+    TQ_STAMP2(0)
     __syncthreads();
+    TQ_STAMP2(1)
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q)
-      if (ej[q] >= 0) tq_adam_replay_tab_given(a, ej[q], es0[q], s1, s_bias, T0, ep[q], em[q], ev[q]);
+    for (int q = 0; q < NPASS; ++q) {
+      if (G > 1 && q == NPASS - 1) tq_adam_replay_split<G>(a, ej[q], es0[q], s1, s_bias, T0, ep[q], em[q], ev[q], tid % G);
+      else if (ej[q] >= 0) tq_adam_replay_tab_given(a, ej[q], es0[q], s1, s_bias, T0, ep[q], em[q], ev[q]);
+      if (q == 0) { TQ_STAMP2(2) }
+    }
+    TQ_STAMP2(3)
     __syncthreads();
   }
   TQ_STAMP(1)
