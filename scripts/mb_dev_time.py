@@ -25,6 +25,15 @@ didx = [(torch.randperm(400, generator=g)[:nb].to(dev, torch.int32), torch.randp
 for nd, fd in didx[:20]:
     eng.step(nd, fd)
 torch.cuda.synchronize()
+if os.environ.get("SUBSAMPLED"):  # subsamples drawn on the device by the tail workgroup of the previous launch
+    gen = torch.Generator().manual_seed(0)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(len(didx)):
+            assert eng.step_subsampled(nb, fb, gen)
+        torch.cuda.synchronize()
+        print(f"{nb}x{fb}, device-drawn subsamples: {1e6 * (time.perf_counter() - t0) / len(didx):.1f} us/step", flush=True)
 for rep in range(3):
     if os.environ.get("STAMPS"):
         torch.cuda.synchronize()

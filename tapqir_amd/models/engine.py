@@ -678,8 +678,10 @@ class CosmosEngine:
                 and (nb < self.Nt or fb < self.F) and fb * self.C >= 16 and max(self.Nt, self.F) <= 2048  # TQ_SUBSAMPLE_MAX
                 and os.environ.get("TAPQIR_AMD_DEVICE_SUBSAMPLE", "1") != "0"):
             return False
-        st = self.__dict__.setdefault("_sub", {"slots": [torch.zeros(self.Nt + self.F, dtype=torch.int32, device=self.device)
-                                                          for _ in range(2)], "turn": 0, "ready": None})
+        st = self.__dict__.get("_sub")
+        if st is None:  # (not setdefault: its argument -- two device allocations + fills -- would be built at every step)
+            st = self._sub = {"slots": [torch.zeros(self.Nt + self.F, dtype=torch.int32, device=self.device) for _ in range(2)],
+                              "turn": 0, "ready": None}
         cur, Nt = st["turn"], self.Nt
         slot, nxt = st["slots"][cur], st["slots"][1 - cur]
         if st["ready"] != (nb, fb, self.adam_step):
