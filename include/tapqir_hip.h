@@ -260,8 +260,9 @@ typedef struct {
                                   tq_cosmos_minibatch_step; [3] completion ticket of the per-AOI sums of a full-batch step with
                                   rows (tq_cosmos_elbo_grads / tq_cosmos_tail; without `sync` those take the flat layout / the
                                   single-workgroup tail); [40] count of the row groups added inside the sampling launch of
-                                  tq_cosmos_step_overlapped (without `sync` its tail workgroup adds all rows itself).  Every
-                                  launch leaves the counters re-armed. */
+                                  tq_cosmos_step_overlapped (without `sync` its tail workgroup adds all rows itself); [60..62] of
+                                  tq_cosmos_minibatch_step: which workgroup runs the tail, the second flag (global draws after the
+                                  gain) and the gain of the launch.  Every launch leaves the counters re-armed. */
   int32_t sync_value;          /* value the flag takes in this launch: any value different from the previous launch's on the
                                   same `sync` words (a launch counter of the host) */
   int32_t images_by_slot;      /* 1: `images` is a window holding the AOIs of this batch in batch order (tq_ksmogn_args.images_by_slot):
@@ -330,12 +331,14 @@ int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
  * must be in place; it applies the Adam step of the local parameters and leaves the rows for the tail). */
 int tq_cosmos_pixel_unit(const tq_cosmos_args* a, void* stream);
 /* Minibatch steps (the reference's default operating point is 10 AOIs x 512 frames = 5120 units, main.py:1428-1431) in
- * ONE launch: every workgroup takes 16 units through lazy-Adam catch-up, guide-site draws, likelihood and per-unit terms +
- * Adam; the first workgroup to start also runs the pending tail of `prev` (or nothing) and the global draws of `a`, which
- * the others wait for before their likelihood phase.  Same arithmetic, same RNG streams and same results as
+ * ONE launch: every workgroup takes 16 units (20 with an offset histogram, when that saves a round of the likelihood phase on
+ * the chip's CUs) through lazy-Adam catch-up, guide-site draws, likelihood and per-unit terms + Adam; one more workgroup runs
+ * the pending tail of `prev` (or nothing) and the global draws of `a` -- the gain first, which the others wait for before
+ * their likelihood phase, the rest before their per-unit phase.  Same arithmetic, same RNG streams and same results as
  * tq_cosmos_adam_catchup + tq_cosmos_step_overlapped; the tail of `a` stays pending: pass `a` (with tail_kind =
  * TQ_TAIL_ROWS16) as `prev` of the next step of either kind or to tq_cosmos_tail.  cosmos model, fuse_adam,
- * fb * C >= 16; `sync` must point to 4 zero-initialised int32. */
+ * fb * C >= 16; `sync` must point to TQ_SYNC_WORDS zero-initialised int32 (zeroed again by the host after a launch that was
+ * torn down). */
 int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos_args* prev, void* stream);
 
 /* AOI-sharded runs: everything that follows the all-reduce of gsum (tq_cosmos_globals_grad + tq_cosmos_adam) in one
