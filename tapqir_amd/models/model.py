@@ -5,6 +5,7 @@ arguments, attributes, files and error behaviour).  ``self.svi.step()`` of the r
 """
 
 import logging
+import math
 import random
 from collections import defaultdict, deque
 from pathlib import Path
@@ -165,8 +166,13 @@ class Model:
                     try:
                         # checkpoint iterations need the loss on the host; the others stay asynchronous
                         if not self.iter % 200:
-                            self.iter_loss = self.step()
-                            self.save_checkpoint(writer)
+                            if writer is None or isinstance(writer, _NullWriter):
+                                # the loss, the NaN check and the convergence parameters come to the host in ONE read-back
+                                self.step_async()
+                                self.save_checkpoint(None, _read_loss=True)
+                            else:
+                                self.iter_loss = self.step()
+                                self.save_checkpoint(writer)
                             if use_crit and self.converged:
                                 logger.info(f"Iteration #{self.iter} model converged.")
                                 break
@@ -226,12 +232,26 @@ class Model:
         """dict name -> unconstrained leaf tensor (view into the engine's flat buffer)."""
         return self.engine.named("params")
 
-    def save_checkpoint(self, writer=None):
+    def save_checkpoint(self, writer=None, _read_loss=False):
         eng = self.engine
         eng.join()
+        # Everything a checkpoint needs on the host in one device-to-host copy: [-ELBO, "all parameters finite", the
+        # unconstrained convergence parameters].  As separate reads (loss, isfinite, one .item() per parameter) a checkpoint
+        # stalled the launch queue five times -- about 1 ms per 200 iterations of 52 us each.
+        views = eng.layout.views(eng.params)
+        want = None if writer is not None else [n for n in self.conv_params if n != "-ELBO"]
+        parts = [eng.elbo_out.reshape(1).to(torch.float64), torch.isfinite(eng.params).all().reshape(1).to(torch.float64)]
+        if want is not None:
+            parts += [views[n].reshape(-1).to(torch.float64) for n in want]
+        host = torch.cat(parts).cpu()
+        if _read_loss:
+            loss = -float(host[0])
+            if not math.isfinite(loss):  # as step() (model.py:212 + 220-232: run() restarts from the last checkpoint)
+                raise ValueError(f"Iteration #{getattr(self, 'iter', 0)}. Non-finite loss {loss}")
+            self.iter_loss = loss
         # save only if no NaN values (model.py:245-250).  In an AOI-sharded fit the ranks agree on the outcome, so that
         # all of them roll back to their checkpoints together (the local parameters live on one rank only)
-        bad = not bool(torch.isfinite(eng.params).all())
+        bad = float(host[1]) == 0.0
         if self.collective is not None:
             bad = self.collective.any(bad)
         if bad:
@@ -239,8 +259,18 @@ class Model:
                 if not bool(torch.isfinite(v).all()):
                     raise ValueError("Iteration #{}. Detected NaN values in {}".format(self.iter, k))
             raise ValueError("Iteration #{}. Detected NaN values on another rank".format(self.iter))
-        # (without a tensorboard writer only the convergence parameters -- globals -- are needed)
-        cparams = eng.layout.constrained(eng.params, None if writer is not None else set(self.conv_params))
+        # (without a tensorboard writer only the convergence parameters -- globals -- are needed: transformed on the host
+        # from the values read above)
+        if want is None:
+            cparams = eng.layout.constrained(eng.params, None)
+        else:
+            from torch.distributions import transform_to
+
+            cons, cparams, at = eng.layout.constraints(), {}, 2
+            for n in want:
+                k = views[n].numel()
+                cparams[n] = transform_to(cons[n])(host[at:at + k].reshape(views[n].shape).to(views[n].dtype))
+                at += k
         for name in self.conv_params:
             if name == "-ELBO":
                 self._rolling["-ELBO"].append(self.iter_loss)
@@ -295,8 +325,12 @@ class Model:
         Inside run() a file may be DEFERRED (helper process busy with the previous file, or still starting).  In an
         AOI-sharded fit that decision is made collectively -- if any rank defers, all do -- so that every rank's file holds
         the same iteration: ranks resuming from files of different iterations would disagree on `iter % 200` and issue
-        mismatched collectives.  At most two files in a row are deferred; the third is written synchronously."""
+        mismatched collectives.  Files are deferred for at most TAPQIR_AMD_CKPT_MAX_LAG seconds (default 2) in a row: a
+        helper that takes longer than that is waited for, so the file on disk never falls further behind the fit.  (A
+        bound by COUNT -- "the third file in a row is written synchronously" -- throttled the fit to a third of the
+        writer's speed once a checkpoint interval, 200 x 54 us, had become shorter than the 40 ms a file takes.)"""
         import os
+        import time
 
         self.run_path.mkdir(parents=True, exist_ok=True)
         target = self.run_path / f"{self.name}_model.tpqr"
@@ -314,13 +348,19 @@ class Model:
             defer = w is not None and (w.busy() or not w.ready())
             if self.collective is not None:
                 defer = self.collective.any(defer)
-            if defer and getattr(self, "_ckpt_deferred", 0) < 2:
-                self._ckpt_deferred = getattr(self, "_ckpt_deferred", 0) + 1
+            now = time.monotonic()
+            since = getattr(self, "_ckpt_deferred_since", None)
+            late = since is not None and now - since > float(os.environ.get("TAPQIR_AMD_CKPT_MAX_LAG", "2"))
+            if self.collective is not None:
+                late = self.collective.any(late)
+            if defer and not late:
+                if since is None:
+                    self._ckpt_deferred_since = now
                 self._ckpt_file_stale = True  # a later checkpoint, or the end of run(), writes a newer state
                 return
             if defer:
-                wait = True  # two files in a row were left out already: this one is written before the fit goes on
-        self._ckpt_deferred = 0
+                wait = True  # files have been left out for too long: this one is written before the fit goes on
+        self._ckpt_deferred_since = None
         if w is not None and not w.failed() and (w.busy() or w.ready() or wait):
             try:
                 w.submit(eng.params, eng.exp_avg, eng.exp_avg_sq, self._manifest(), target)

@@ -383,27 +383,38 @@ def _host_model(tmp_path, iters=1):
     return m
 
 
-def test_checkpoint_files_deferred_at_most_twice_and_dead_helper_is_dropped(tmp_path):
+def test_checkpoint_files_deferred_for_a_bounded_time_and_dead_helper_is_dropped(tmp_path, monkeypatch):
     """a helper process that died must not turn every later checkpoint into a deferred one; a busy helper
-    defers at most two files in a row."""
+    defers files for at most TAPQIR_AMD_CKPT_MAX_LAG seconds in a row (a bound by count would tie the fit to the writer once
+    200 iterations take less time than a file)."""
+    import time
+
+    monkeypatch.setenv("TAPQIR_AMD_CKPT_MAX_LAG", "0.3")
     m = _host_model(tmp_path)
     target = tmp_path / ".tapqir" / "cosmos_model.tpqr"
     n = m.engine.params.numel()
     m._in_run = True
-    # busy helper: two deferrals, then the third file is submitted and waited for
+    # busy helper: deferrals while the lag is short (any number of them), then a file is submitted and waited for
     w = m._ckpt_process = _FakeWriter(n, busy=True)
-    for it, want_stale, want_sub in ((200, True, 0), (400, True, 0), (600, False, 1)):
+    for it in (200, 400, 600, 800):
         m.iter = it
         m._write_state_file()
-        assert m._ckpt_file_stale is want_stale and len(w.submitted) == want_sub
-    assert w.submitted == [600]
+        assert m._ckpt_file_stale is True and len(w.submitted) == 0
+    time.sleep(0.35)
+    m.iter = 1000
+    m._write_state_file()
+    assert m._ckpt_file_stale is False and w.submitted == [1000]
+    # ... and the clock starts again with the next deferral
+    m.iter = 1200
+    m._write_state_file()
+    assert m._ckpt_file_stale is True and w.submitted == [1000]
     # a helper that is gone: dropped, the file is written in-process at once
     m._ckpt_process = dead = _FakeWriter(n, dead=True)
-    m.iter = 800
+    m.iter = 1400
     target.unlink()
     m._write_state_file()
     assert dead.closed and m._ckpt_process is None and not m._ckpt_file_stale
-    assert torch.load(target, weights_only=False)["iter"] == 800
+    assert torch.load(target, weights_only=False)["iter"] == 1400
     m._in_run = False
 
 
