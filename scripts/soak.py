@@ -1,5 +1,7 @@
 """Soak run: 10 000 full-batch steps, 40 000 minibatch steps with fresh subsamples, 300 steps alternating between the two kinds
-(pending tails handed from one kind to the other); everything must stay finite and no launch may stall."""
+(pending tails handed from one kind to the other), 20 000 steps on device-drawn subsamples, 20 000 minibatch steps with a 50-value
+offset histogram (20 units per workgroup, tail claimed by the last block); everything must stay finite, no launch may stall and no
+workgroup may ever have given up waiting for a flag (sync word 63)."""
 import os, sys, time, torch
 sys.path.insert(0, ".")
 from tapqir_amd.models.cosmos import initial_values
@@ -33,3 +35,20 @@ for it in range(20000):
     assert e.step_subsampled(10, 512, g)
 e.join(); torch.cuda.synchronize()
 print("device-subsampled 20000 steps", round(time.time() - t0, 2), "s; ELBO", float(e.elbo_out[0]), "finite", bool(torch.isfinite(e.params).all()))
+print("workgroups that gave up waiting for a flag:", int(e._sync[63]))
+# offset histogram: 257 workgroups of 20 units, the tail on the block dispatched last, two flags
+from tapqir_amd.utils.dataset import CosmosDataset
+s_ = torch.arange(70.0, 120.0)
+w_ = torch.minimum(s_ - 69.0, 120.0 - s_)
+h = CosmosEngine(CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s_, offset_weights=w_ / w_.sum()), K=2, device=dev, seed=7)
+h.layout.set_constrained(h.params, initial_values(h, data))
+t0 = time.time()
+bad = 0
+for it in range(20000):
+    assert h.step_subsampled(10, 512, g)
+    if it % 100 == 99:
+        h.join()
+        bad += int(not torch.isfinite(h.elbo_out).all())
+h.join(); torch.cuda.synchronize()
+print("histogram minibatch 20000 steps", round(time.time() - t0, 2), "s; ELBO", float(h.elbo_out[0]), "finite", bool(torch.isfinite(h.params).all()),
+      "non-finite losses seen", bad, "workgroups that gave up waiting:", int(h._sync[63]))

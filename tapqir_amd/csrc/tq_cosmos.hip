@@ -545,6 +545,7 @@ __global__ __launch_bounds__(TQ_UNIT_BLOCK) void tq_unit_rows_kernel(const tq_co
 #define TQ_GRP_UNITS 4096
 #define TQ_GRP_AOIS (TQ_GRP_UNITS / TQ_UNIT_BLOCK + 1)   /* AOIs a group can touch (F * C >= TQ_UNIT_BLOCK) */
 #define TQ_GGROW (2 * 16 + TQ_GRP_AOIS * 2 * TQ_MAXQ)    /* floats of a group row: 16 doubles, then 2 * TQ_MAXQ floats per AOI */
+#define TQ_SYNC_LOST 63                                  /* workgroups that gave up waiting for a flag, ever (diagnostics; never observed) */
 #define TQ_SYNC_GAIN 62                                  /* the gain of a minibatch launch (float bits), published with the first flag */
 #define TQ_SYNC_FLAG2 61                                 /* second flag of a minibatch launch: the global draws after the gain */
 #define TQ_SYNC_CLAIM 60                                 /* word that names the workgroup running the tail of a minibatch launch (tail_last) */
@@ -1314,7 +1315,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     constexpr int NPASS = (NL * U + 255) / 256;
     // a thin last pass is shared out: G lanes per element (tq_adam_replay_split)
     constexpr int XLAST = NL * U - 256 * (NPASS - 1);
+#ifdef TQ_NO_REPLAY_SPLIT
+    constexpr int G = 1;
+#else
     constexpr int G = NPASS == 1 ? 1 : (XLAST <= 32 ? 8 : (XLAST <= 64 ? 4 : (XLAST <= 128 ? 2 : 1)));
+#endif
     int64_t ej[NPASS];
     int es0[NPASS];
     float ep[NPASS], em[NPASS], ev[NPASS];
@@ -1411,6 +1416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       // checkpoint (model.py:220-232); CosmosEngine.reset_adam_clock zeroes the sync words on that path.
       a.blk_part[wblk * (TQ_ROWS_GCOL + tq_num_gsum(a)) + TQ_ROWS_GCOL + TQ_GS_ELBO] = __builtin_nanf("");
       a.elbo_out[0] = __builtin_nan("");
+      __hip_atomic_fetch_add(&a.sync[TQ_SYNC_LOST], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (never reset: a soak run reads it)
       count_out();  // still counted: the ticket counter is re-armed for the launches that follow
     }
   };

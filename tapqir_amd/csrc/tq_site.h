@@ -214,9 +214,13 @@ TQ_HD void tq_affine_beta_site_terms(float y, float mean, float size, float low,
 TQ_HD void tq_gamma_site_chain(const float* s, float v, float loc, float beta, float e_v, float wq, float* d_loc_u,
                                float* d_beta_u) {
   const float alpha = loc * beta;
-  const float ev_tot = e_v - wq * s[1];
-  const float g_alpha = ev_tot * s[4] - wq * s[2];
-  const float g_beta_direct = ev_tot * (-v * TQ_FRCP(beta)) - wq * s[3];
+  // d lq/d v = (alpha - 1)/v - beta reaches 3e37 when a draw of a Gamma with alpha < 1 lands on the clamp at the smallest
+  // normal number (height of an absent spot in a converged fit: seen once in ~7000 minibatch steps); times the plate
+  // scale Nt F / (nb fb) ~ 80 it overflows, and inf * (dv/dalpha ~ 1e-36) - inf made the height parameters NaN.  The
+  // products are formed so that the large and the small factor meet first: s[1] s[4] = O(1), s[1] v = (alpha - 1) - beta v.
+  const float g_alpha = (e_v * s[4] - wq * (s[1] * s[4])) - wq * s[2];
+  const float s1v = (alpha - 1.0f) - beta * v;
+  const float g_beta_direct = (wq * s1v - e_v * v) * TQ_FRCP(beta) - wq * s[3];
   *d_loc_u = g_alpha * alpha;                          // alpha = loc*beta; loc = exp(u_loc)
   *d_beta_u = g_alpha * alpha + g_beta_direct * beta;  // beta = exp(u_beta)
 }

@@ -84,6 +84,57 @@ def test_dead_pixel_crosstalk_hip(il):
     _check(*_run("cuda:0", None, "sim", il_min_units=il, crosstalk=True), crosstalk=True)
 
 
+def _clamped_height(device, lib):
+    """A height draw on the clamp at the smallest normal float (Gamma with concentration < 1: the height of an absent spot in
+    a converged fit; torch's rsample clamps there too) in a minibatch whose plate scale is 40: d log q / d v = (alpha - 1) / v
+    is -3e37 and, scaled, left the range of float32 -- inf * (dv / dalpha ~ 1e-36) - inf made the unit's height parameters
+    NaN once in ~7000 steps of a fit (tq_gamma_site_chain).  Every gradient must be finite and agree with the oracle."""
+    from helpers import oracle_grads, rel_err
+
+    K, N, F = 2, 8, 20
+    d = make_dataset(N=N, F=F, K=K)
+    o = make_oracle(d, K)
+    nd, fd = torch.tensor([1, 5]), torch.tensor([0, 3, 7, 12])
+    tiny = 1.1754943508222875e-38
+    with torch.no_grad():
+        o.params["h_loc"][1, 5, 7, 0] = torch.tensor(468.0).log()
+        o.params["h_beta"][1, 5, 7, 0] = torch.tensor(0.00138).log()
+        o.params["m_probs"][1, 5, 7, 0] = 4.0  # the guide believes in the spot: its weight in the per-unit terms is ~1
+    eng = CosmosEngine(d, K=K, device=device, lib=lib)
+    oracle_to_engine(o, eng)
+    lat32, base = fp32_latents(o, nd, fd)
+    lat32["height"][1, 1, 2, 0] = tiny  # position (AOI 5, frame 7) of the batch
+    with torch.no_grad():
+        base = o.base_draws(lat32, o._guide_dists(o.constrained(o.params), nd, fd))
+    elbo_o, g_o = oracle_grads(o, nd, fd, base)
+    a = eng.make_args(nd, fd, draw_globals=False)
+    put_latents(eng, lat32, base)
+    for stage in GIVEN_STAGES:
+        eng.call(stage, a)
+    if eng.device.type == "cuda":
+        torch.cuda.synchronize()
+    assert abs(float(eng.elbo_out[0]) - elbo_o) <= 2e-5 * abs(elbo_o)
+    gv = eng.named("grad")
+    for n, ref in g_o.items():
+        got = gv[n].cpu().double().reshape(ref.shape)
+        assert bool(torch.isfinite(got).all()), n
+        if n in ("h_loc", "h_beta"):
+            # the clamped unit: dv/dalpha is taken at a DENORMAL standard-gamma value (v beta = 1.6e-41) in fp32
+            assert abs(float(got[1, 5, 7, 0]) - float(ref[1, 5, 7, 0])) <= 0.05 * abs(float(ref[1, 5, 7, 0])), (n, got[1, 5, 7, 0], ref[1, 5, 7, 0])
+            got, ref = got.clone(), ref.clone()
+            got[1, 5, 7, 0] = ref[1, 5, 7, 0] = 0.0
+        assert rel_err(got, ref) < 1e-4, (n, rel_err(got, ref))
+
+
+def test_height_draw_on_the_clamp_host_math():
+    _clamped_height("cpu", load_hostcheck())
+
+
+@pytest.mark.gpu
+def test_height_draw_on_the_clamp_hip():
+    _clamped_height("cuda:0", None)
+
+
 def test_abi_rejects_malformed_arguments():
     """No launch, TQ_ERR_ARG (= 1) and a message; checked on the CPU (the checks run before any HIP call)."""
     lib = _lib.load()
