@@ -6,13 +6,14 @@ from tapqir_amd.models.engine import CosmosEngine
 from tapqir_amd.utils.dataset import CosmosDataset
 from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
 dev = torch.device("cuda", 0)
-class _M: K, device = 2, dev
+KK = int(os.environ.get("K", 2))
+class _M: K, device = KK, dev
 data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
 s_ = torch.arange(70.0, 120.0)
 w_ = torch.minimum(s_ - 69.0, 120.0 - s_)
 if os.environ.get("OFFSETS", "hist") == "hist":
     data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s_, offset_weights=w_ / w_.sum())
-h = CosmosEngine(data, K=2, device=dev, seed=int(os.environ.get("SEED", 7)))
+h = CosmosEngine(data, K=KK, device=dev, seed=int(os.environ.get("SEED", 7)))
 h.layout.set_constrained(h.params, initial_values(h, data))
 g = torch.Generator().manual_seed(0)
 steps, every = int(os.environ.get("STEPS", 20000)), int(os.environ.get("EVERY", 50))
