@@ -270,7 +270,7 @@ typedef struct {
   int32_t* next_ndx;           /* tq_cosmos_minibatch_step: [nb] or NULL, and */
   int32_t* next_fdx;           /* [fb] or NULL -- the launch also draws the NEXT step's subsample, `randperm(Nt)[:nb]` /
                                   `randperm(F)[:fb]` of pyro.plate (cosmos.py:194-208), as the nb / fb smallest of Nt / F Philox
-                                  keys (stream: seed, step + 1) in its tail workgroup, after the flag is published: a host that
+                                  keys (stream: seed, step + 1; a radix selection, no sort) in its tail workgroup, after the flags are published: a host that
                                   passes them as ndx / fdx of the next call never draws, stages or copies an index
                                   (Nt, F <= TQ_SUBSAMPLE_MAX) */
 } tq_cosmos_args;

@@ -1042,38 +1042,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
 // tq_cosmos_tail).
 // =============================================================================================================
 // The next step's subsample, drawn by the tail workgroup of a minibatch launch: `take` of `n` indices without replacement =
-// the indices of the `take` smallest of n Philox keys (stream: seed, step, site), by a bitonic sort of (key << 32 | index)
-// in LDS (256 threads, n <= TQ_SUBSAMPLE_MAX; `buf` holds 2 * pow2(n) uint32 words).  The law of randperm(n)[:take]
-// (pyro.plate's subsample, cosmos.py:194-208) up to the order of the selected indices, which no sum depends on.
-__device__ __forceinline__ void tq_draw_subsample(uint64_t* buf, uint64_t seed, uint32_t step, uint32_t site, int n, int take,
+// the indices of the `take` smallest of n Philox keys (stream: seed, step, site; ties broken by the index).  The law of
+// randperm(n)[:take] (pyro.plate's subsample, cosmos.py:194-208) up to the order of the selected indices, which no sum depends
+// on.  256 threads, n <= TQ_SUBSAMPLE_MAX = 2048 (eight keys per thread, in registers); `hist` holds 2048 + 8 int32 words.
+//
+// Selection by radix instead of a sort (a bitonic sort of 1024 keys in LDS is 55 barrier-separated stages, ~2.5 us of every
+// step): a histogram of the top 11 bits of the 43-bit composite (key << 11 | index), a scan over its bins to the bin that
+// holds the take-th smallest, and -- only if that bin is not taken whole -- the same again on the next 11 bits inside it
+// (random keys: the boundary bin holds one or two elements, so one or two levels).  Then the selected indices are
+// compacted in (thread, slot) order through a second scan: the output does not depend on the timing of any atomic.
+__device__ __forceinline__ int tq_block_exscan(int v, int* s_w) {  // exclusive prefix sum over the 256 threads; s_w: 4 words
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  __syncthreads();  // (the previous use of s_w has been read)
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (w < wave) base += s_w[w];
+  return base + inc - v;
+}
+__device__ __forceinline__ void tq_draw_subsample(int* hist, uint64_t seed, uint32_t step, uint32_t site, int n, int take,
                                                   int32_t* out) {
-  int n2 = 1;
-  while (n2 < n) n2 <<= 1;
-  for (int i = threadIdx.x; i < n2; i += 256) {
-    uint64_t key = ~0ull;
+  constexpr int PER = TQ_SUBSAMPLE_MAX / 256;
+  int* s_w = hist + 2048;      // 4 words of the scans
+  int* s_bnd = hist + 2048 + 4;  // boundary bin, elements below it, elements in it
+  const int tid = threadIdx.x;
+  uint64_t c[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid + 256 * j;
+    c[j] = ~0ull;
     if (i < n) {
       TqPhilox s;
       tq_philox_init(&s, seed, step, site, (uint64_t)i);
-      key = ((uint64_t)tq_philox_next(&s) << 32) | (uint32_t)i;
+      c[j] = ((uint64_t)tq_philox_next(&s) << 11) | (uint32_t)i;
     }
-    buf[i] = key;
   }
-  __syncthreads();
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (n2 >> 1); t += 256) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-        const uint64_t x = buf[lo], y = buf[hi];
-        const bool up = (lo & k) == 0;
-        if ((x > y) == up) {
-          buf[lo] = y;
-          buf[hi] = x;
-        }
+  uint64_t path = 0, T = 0;
+  int need = take;
+  for (int level = 0; level < 4; ++level) {
+    const int shift = level == 0 ? 32 : (level == 1 ? 21 : (level == 2 ? 10 : 0));
+    const int width = level == 3 ? 10 : 11;
+    for (int b = tid; b < 2048; b += 256) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (tid + 256 * j < n && (c[j] >> (shift + width)) == path) atomicAdd(&hist[(int)((c[j] >> shift) & ((1u << width) - 1u))], 1);
+    __syncthreads();
+    int cnt[8], local = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      cnt[q] = hist[8 * tid + q];
+      local += cnt[q];
+    }
+    int run = tq_block_exscan(local, s_w);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (run < need && run + cnt[q] >= need) {
+        s_bnd[0] = 8 * tid + q;
+        s_bnd[1] = run;
+        s_bnd[2] = cnt[q];
       }
-      __syncthreads();
+      run += cnt[q];
     }
+    __syncthreads();
+    const int b = s_bnd[0], below = s_bnd[1], inbin = s_bnd[2];
+    path = (path << width) | (uint64_t)b;
+    need -= below;
+    if (inbin == need) {  // the boundary bin is taken whole (always at the last level: composites are distinct)
+      T = (path + 1) << shift;
+      break;
+    }
+    __syncthreads();  // (s_bnd is rewritten at the next level)
   }
-  for (int t = threadIdx.x; t < take; t += 256) out[t] = (int32_t)(uint32_t)buf[t];
+  int mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) mine += (tid + 256 * j < n && c[j] < T) ? 1 : 0;
+  int at = tq_block_exscan(mine, s_w);
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
+    if (tid + 256 * j < n && c[j] < T) out[at++] = (int32_t)(tid + 256 * j);
+  __syncthreads();  // (hist is reused by the next draw)
 }
 #define TQ_SITE_SUBSAMPLE_N 0xA00u
 #define TQ_SITE_SUBSAMPLE_F 0xA01u
@@ -1292,10 +1348,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     TQ_TAIL_STAMP(11)
     // the NEXT step's subsample (nobody waits for it: the next launch reads it)
     if (a.next_ndx && a.nb < a.Nt) {
-      tq_draw_subsample((uint64_t*)smem, a.seed, a.step + 1, TQ_SITE_SUBSAMPLE_N, a.Nt, a.nb, a.next_ndx);
+      tq_draw_subsample((int*)smem, a.seed, a.step + 1, TQ_SITE_SUBSAMPLE_N, a.Nt, a.nb, a.next_ndx);
       __syncthreads();
     }
-    if (a.next_fdx && a.fb < a.F) tq_draw_subsample((uint64_t*)smem, a.seed, a.step + 1, TQ_SITE_SUBSAMPLE_F, a.F, a.fb, a.next_fdx);
+    if (a.next_fdx && a.fb < a.F) tq_draw_subsample((int*)smem, a.seed, a.step + 1, TQ_SITE_SUBSAMPLE_F, a.F, a.fb, a.next_fdx);
     if (tid == 0) count_out();
     return;
   }
@@ -1898,8 +1954,8 @@ extern "C" int tq_cosmos_minibatch_step(const tq_cosmos_args* a, const tq_cosmos
       tq_set_error("tq_cosmos_minibatch_step: next_ndx / next_fdx need Nt, F <= TQ_SUBSAMPLE_MAX");
       return TQ_ERR_ARG;
     }
-    const size_t sort = 2 * sizeof(uint64_t) * TQ_SUBSAMPLE_MAX / 2;  // pow2(n) <= TQ_SUBSAMPLE_MAX keys of 8 bytes
-    if (lds < sort) lds = sort;
+    const size_t sel = sizeof(int) * (2048 + 8);  // tq_draw_subsample: histogram of 2048 bins + scan / boundary words
+    if (lds < sel) lds = sel;
   }
   const int code = prev ? tq_prev_code(*prev) : 0;
   const tq_cosmos_args& pv = prev ? *prev : *a;
