@@ -1028,17 +1028,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
 // The reference's default operating point (10 AOIs x 512 frames, main.py:1428-1431) is 5120 units: 80 waves of work for
 // a chip with 4096 wave slots.  As five launches (lazy-Adam catch-up, site draws + previous tail, likelihood, per-unit,
 // per-AOI) a step costs five launch latencies on the device (70 us) and about as much on the host, which becomes the
-// bottleneck.  Here ONE launch runs a step; a workgroup owns 16 units through all phases:
-//   ticket 0 only : tail of the PREVIOUS step (cross-unit sums, per-AOI sites, global sites, ELBO, Adam of the per-AOI /
-//                   global parameters), then the global draws of this step; publishes a flag (device-scope release);
-//   phase 1       : lazy-Adam catch-up of the 16 units' local parameters, then their 9 x 16 guide-site draws;
-//   (wait)        : one lane polls the flag (the likelihood needs this step's gain, the per-unit terms its tables);
-//   phase 2       : the 16-lanes-per-unit likelihood routine of tq_ksmogn_kernel (tq_ksmogn_tile16);
+// bottleneck.  Here ONE launch runs a step; a workgroup owns U = 16 units (20 with an offset histogram: tq_mb_upr) through
+// all phases:
+//   tail workgroup: tail of the PREVIOUS step (cross-unit sums, per-AOI sites, global sites, ELBO, Adam of the per-AOI /
+//                   global parameters) and the global draws of this step, the GAIN's chain first: flag 1 (device-scope
+//                   release) when the gain is drawn, flag 2 when the other draws are; then the next step's subsample
+//                   (tq_draw_subsample).  Ticket 0, or the block dispatched last if it claims the role (tail_last);
+//   phase 1       : lazy-Adam catch-up of the U units' local parameters, then their 9 x U guide-site draws;
+//   (wait 1)      : one lane polls flag 1 (the likelihood needs this step's gain);
+//   phase 2       : the 16-lanes-per-unit likelihood routine of tq_ksmogn_kernel (tq_ksmogn_tile_at); of 20 units the
+//                   last four with a wave each;
+//   (wait 2)      : flag 2 (the per-unit terms need the tables of pi, lamda, proximity: set long before);
 //   phase 3       : per-unit ELBO terms, gradients and Adam (one lane per unit), row of partial sums with the per-AOI
-//                   frame sums folded in (rows of 16 units, tq_rows_reduce_globals_body<16>).
+//                   frame sums folded in (rows of U units, tq_rows_reduce_globals_body<16>).
 // Phases hand data over through the step workspace in global memory; a workgroup lives on one CU, whose L1 its waves
-// share, so a workgroup barrier orders those accesses.  The ticket-0 workgroup never waits for another one, so the
-// waiting workgroups cannot deadlock whatever the dispatch order.  The tail of THIS step runs in the next launch (or in
+// share, so a workgroup barrier orders those accesses.  The tail workgroup never waits for a workgroup that may not be
+// resident yet, so the waiting workgroups cannot deadlock whatever the dispatch order.  The tail of THIS step runs in the next launch (or in
 // tq_cosmos_tail).
 // =============================================================================================================
 // The next step's subsample, drawn by the tail workgroup of a minibatch launch: `take` of `n` indices without replacement =
