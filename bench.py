@@ -657,6 +657,23 @@ def worker(args):
         mb = sorted(mbs)[2]
         out["minibatch_10x512"] = {"ms_per_step": mb * 1e3, "steps_per_sec": 1 / mb, "aoi_frames_per_sec": nb * fb / mb,
                                    "protocol": "median of 5 blocks of 100 steps, fresh random subsample every step"}
+        # the path of Model.run: the subsample of step t + 1 drawn on the device by the launch of step t
+        # (CosmosEngine.step_subsampled; falls back to the figures above where that path does not apply)
+        if eng.step_subsampled(nb, fb, g):
+            for _ in range(20):
+                eng.step_subsampled(nb, fb, g)
+            dss = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    eng.step_subsampled(nb, fb, g)
+                eng.join()
+                torch.cuda.synchronize()
+                dss.append((time.perf_counter() - t0) / 100)
+            ds = sorted(dss)[2]
+            out["minibatch_10x512"]["device_subsampled"] = {"ms_per_step": ds * 1e3, "steps_per_sec": 1 / ds,
+                                                            "aoi_frames_per_sec": nb * fb / ds}
         # ---- trained-parameter regime: guide concentrations shrink as the fit converges and other regimes of the
         # implicit reparameterisation gradients take over ------------------------------------
         if args.trained_steps > 0 and cfg == "c2" and args.offsets == "sim":

@@ -331,8 +331,7 @@ int tq_cosmos_tail(const tq_cosmos_args* a, void* stream);
  * must be in place; it applies the Adam step of the local parameters and leaves the rows for the tail). */
 int tq_cosmos_pixel_unit(const tq_cosmos_args* a, void* stream);
 /* Minibatch steps (the reference's default operating point is 10 AOIs x 512 frames = 5120 units, main.py:1428-1431) in
- * ONE launch: every workgroup takes 16 units (20 with an offset histogram, when that saves a round of the likelihood phase on
- * the chip's CUs) through lazy-Adam catch-up, guide-site draws, likelihood and per-unit terms + Adam; one more workgroup runs
+ * ONE launch: every workgroup takes 16 units (20 when that saves a round of workgroups on the chip's CUs) through lazy-Adam catch-up, guide-site draws, likelihood and per-unit terms + Adam; one more workgroup runs
  * the pending tail of `prev` (or nothing) and the global draws of `a` -- the gain first, which the others wait for before
  * their likelihood phase, the rest before their per-unit phase.  Same arithmetic, same RNG streams and same results as
  * tq_cosmos_adam_catchup + tq_cosmos_step_overlapped; the tail of `a` stays pending: pass `a` (with tail_kind =

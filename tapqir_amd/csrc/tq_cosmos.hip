@@ -453,16 +453,15 @@ static bool tq_rows_layout(const tq_cosmos_args& a) {
 // the last four with a wave each, when that takes fewer rounds of pixel iterations on the chip's 256 CUs.  A workgroup
 // keeps one wave per SIMD busy for 13 iterations of P = 14 (196 pixels on 16 lanes), 17 with 20 units (+ 4: 196 pixels on 64
 // lanes); a CU that hosts two workgroups takes twice as long, and the default 10 x 512 minibatch is 320 workgroups of 16
-// units -- 64 CUs with two, 26 iterations on the critical path -- but 256 of 20: 17.  A pure function of the batch geometry
-// (TAPQIR_AMD_MB_UNITS = 16 / 20 overrides): the launch that runs the pending tail of the step calls it again.
+// units -- 64 CUs with two, 26 iterations on the critical path -- but 256 of 20: 17.  With a single camera offset the phase is
+// short, but every phase of a workgroup that shares its CU is slower: 49.5 -> 44.7 us per step with 20 (once the gain has its
+// own flag; before that the tail workgroup next to a worker delayed everybody and 20 lost, 55.5 against 53.0).  A pure function
+// of the batch geometry (TAPQIR_AMD_MB_UNITS = 16 / 20 overrides): the launch that runs the pending tail calls it again.
 static int tq_mb_upr(const tq_cosmos_args& a) {
   const char* e = getenv("TAPQIR_AMD_MB_UNITS");  // (read at every call: tests switch it inside one process)
   const int forced = e ? atoi(e) : 0;
   if ((int64_t)a.fb * a.C < 20 || forced == 16) return 16;
   if (forced == 20) return 20;
-  // (single offset: the likelihood phase is 8 us of a 40 us workgroup and the second pass adds latency -- 55.5 against
-  // 53.0 us per step measured with 20)
-  if (a.O < 8) return 16;
   const int64_t B = tq_batch_units(a);
   const int64_t r16 = ((B + 15) / 16 + 255) / 256, r20 = ((B + 19) / 20 + 255) / 256;
   return 17 * r20 < 13 * r16 ? 20 : 16;
@@ -1028,7 +1027,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
 // The reference's default operating point (10 AOIs x 512 frames, main.py:1428-1431) is 5120 units: 80 waves of work for
 // a chip with 4096 wave slots.  As five launches (lazy-Adam catch-up, site draws + previous tail, likelihood, per-unit,
 // per-AOI) a step costs five launch latencies on the device (70 us) and about as much on the host, which becomes the
-// bottleneck.  Here ONE launch runs a step; a workgroup owns U = 16 units (20 with an offset histogram: tq_mb_upr) through
+// bottleneck.  Here ONE launch runs a step; a workgroup owns U = 16 or 20 units (tq_mb_upr) through
 // all phases:
 //   tail workgroup: tail of the PREVIOUS step (cross-unit sums, per-AOI sites, global sites, ELBO, Adam of the per-AOI /
 //                   global parameters) and the global draws of this step, the GAIN's chain first: flag 1 (device-scope
