@@ -720,6 +720,14 @@ class CosmosEngine:
         # 0.150 against 0.162 ms at O = 50 -- TAPQIR_AMD_MB_HIST_STAGED=1 -- not worth a second path through the step)
         one_launch = (minibatch and self.lazy_adam and self.fused_minibatch and allreduce is None and not self.crosstalk
                       and a.fb * self.C >= 16 and not (self.O >= 8 and os.environ.get("TAPQIR_AMD_MB_HIST_STAGED") == "1"))
+        # a SMALL full batch (BASELINE config c1: 5000 units) is the same case as a minibatch -- a few hundred workgroups
+        # whose every phase is latency: the one-launch step with no subsample and no lazy clock instead of the two launches
+        # of the pipelined full-batch step (TAPQIR_AMD_SMALL_FULL=0: the two launches)
+        B_full = self.Nt * self.F * self.C
+        if (not minibatch and self.fused_minibatch and self.pipelined_tail and allreduce is None and not self.crosstalk
+                and B_full <= 10240 and B_full < self.il_min_units and self.F * self.C >= 16
+                and os.environ.get("TAPQIR_AMD_SMALL_FULL", "1") != "0"):
+            one_launch = True
         if minibatch and self.lazy_adam:
             if not self._stale:
                 self._last_step.fill_(self.adam_step)  # every unit is current: start the clock here

@@ -199,11 +199,35 @@ def test_c1_full_size_elbo_and_every_gradient():
 
 @pytest.mark.parametrize("minibatch", [False, True], ids=["full_batch", "minibatch_5x64"])
 def test_c1_full_size_steps(minibatch):
-    """c1 through CosmosEngine.step with nothing overridden (what `tapqir fit` runs for it): whole-batch steps (16-lane
-    pixel kernel, flat per-unit kernel, per-AOI kernel, pipelined tail) and minibatch steps in one launch."""
+    """c1 through CosmosEngine.step with nothing overridden (what `tapqir fit` runs for it): whole-batch steps -- a batch of
+    5000 units takes the one-launch step of the minibatches (no subsample, no lazy clock; 250 workgroups of 20 units) -- and
+    minibatch steps in one launch."""
     K, N, F = 1, 50, 100
     d, o, eng = setup(K, dict(N=N, F=F))
+    calls = []
+    real = eng.lib.tq_cosmos_minibatch_step
+
+    class Spy:
+        def __getattr__(self, n):
+            if n == "tq_cosmos_minibatch_step":
+                def f(*a):
+                    calls.append(1)
+                    return real(*a)
+                return f
+            return getattr(eng_lib, n)
+
+    eng_lib, eng.lib = eng.lib, Spy()
     replay(eng, o, N, F, **(dict(nb=5, fb=64) if minibatch else {}))
+    assert len(calls) == 3
+
+
+def test_c1_full_size_steps_two_launches(monkeypatch):
+    """The same whole-batch steps through the pipelined two-launch sequence (16-lane pixel kernel, flat per-unit kernel,
+    per-AOI kernel, tail inside the next sampling launch), which TAPQIR_AMD_SMALL_FULL=0 keeps available."""
+    monkeypatch.setenv("TAPQIR_AMD_SMALL_FULL", "0")
+    K, N, F = 1, 50, 100
+    d, o, eng = setup(K, dict(N=N, F=F))
+    replay(eng, o, N, F)
 
 
 # ---- (d) the AOI-sharded launch sequence with the fused kernel -----------------------------------------------------------
