@@ -11,7 +11,11 @@ class _M: K, device = KK, dev
 data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
 s_ = torch.arange(70.0, 120.0)
 w_ = torch.minimum(s_ - 69.0, 120.0 - s_)
-if os.environ.get("OFFSETS", "hist") == "hist":
+if os.environ.get("OFFSETS") == "wide":  # offsets reaching above the dimmest pixels: masked offsets in most pixels' loops
+    s_ = torch.arange(70.0, 330.0, 4.0)
+    w_ = torch.exp(-0.5 * ((s_ - 90.0) / 60.0) ** 2)
+    data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s_, offset_weights=(w_ / w_.sum()).float())
+elif os.environ.get("OFFSETS", "hist") == "hist":
     data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s_, offset_weights=w_ / w_.sum())
 h = CosmosEngine(data, K=KK, device=dev, seed=int(os.environ.get("SEED", 7)))
 h.layout.set_constrained(h.params, initial_values(h, data))

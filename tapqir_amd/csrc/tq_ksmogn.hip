@@ -466,7 +466,7 @@ __device__ __forceinline__ void tq_pair_multi_offset(TqPixAcc<K>& A, const tq_ks
       const tq_f2 t = mu[mi] - g;
       vs[mi] = (tq_f2){fminf(fmaxf(t.x, vlo.x), vhi.x), fminf(fmaxf(t.y, vlo.y), vhi.y)};
       av[mi] = mu[mi] * rg - 1.0f;
-      cv[mi] = -av[mi] * tq2_log2(vs[mi] * rvhi);
+      cv[mi] = -av[mi] * tq2_log2(vs[mi] * rvhi) - (rg * TQ_LOG2E) * (vhi - vs[mi]);  // (as tq_mo_reference)
       S0[mi] = S1[mi] = S2[mi] = tq2(0.0f);
     }
 #pragma unroll 4
@@ -601,9 +601,8 @@ __device__ __forceinline__ void tq_il2m_pixel_loop(TqPixAcc<K>& A, const tq_ksmo
 }
 
 template <int K, bool BWD>
-__global__ __launch_bounds__(256) void tq_ksmogn_il2m_kernel(const tq_ksmogn_args a, const int64_t B) {
+__device__ __forceinline__ void tq_il2m_body(const tq_ksmogn_args& a, const int64_t B, float2* s_tab) {
   constexpr int M = 1 << K;
-  __shared__ float2 s_tab[TQ_MO_MAX_O];
   const int64_t i_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i_raw < B;
   const int64_t i = live ? i_raw : (B - 1);
@@ -660,6 +659,19 @@ __global__ __launch_bounds__(256) void tq_ksmogn_il2m_kernel(const tq_ksmogn_arg
     }
     tq_pixel_store<K, false, BWD>(a, B, i, A, W, b, rg, hk, wk, cxs, cys, (float)npix, 0.0f, false);
   }
+}
+// K <= 2 with the cap of two waves per SIMD: at K = 2 with the backward the allocator lands on 270 registers without it (since
+// the reference constant moved into the exponent), a second wave no longer fits and the launch takes 18 % longer; 13 spilled
+// registers with it.  K >= 3 would spill hundreds under the cap and keeps one wave.
+template <int K, bool BWD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void tq_ksmogn_il2m_kernel(const tq_ksmogn_args a, const int64_t B) {
+  __shared__ float2 s_tab[TQ_MO_MAX_O];
+  tq_il2m_body<K, BWD>(a, B, s_tab);
+}
+template <int K, bool BWD>
+__global__ __launch_bounds__(256) void tq_ksmogn_il2m_wide_kernel(const tq_ksmogn_args a, const int64_t B) {
+  __shared__ float2 s_tab[TQ_MO_MAX_O];
+  tq_il2m_body<K, BWD>(a, B, s_tab);
 }
 
 // (U, npix) row-major tiles -> the interleaved layout above; out holds ceil(U/64) * npix4 * 256 floats
@@ -775,8 +787,13 @@ static int launch_kb(const tq_ksmogn_args& a, int64_t B, hipStream_t st) {
       return launch_status("tq_ksmogn_il2_kernel");
     }
     if (!ONE && (a.P % 2) == 0 && a.O <= TQ_MO_MAX_O) {
-      if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2m_kernel<K, true>), grid, block, 0, st, a, B);
-      else hipLaunchKernelGGL((tq_ksmogn_il2m_kernel<K, false>), grid, block, 0, st, a, B);
+      if constexpr (K <= 2) {
+        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2m_kernel<K, true>), grid, block, 0, st, a, B);
+        else hipLaunchKernelGGL((tq_ksmogn_il2m_kernel<K, false>), grid, block, 0, st, a, B);
+      } else {
+        if (bwd) hipLaunchKernelGGL((tq_ksmogn_il2m_wide_kernel<K, true>), grid, block, 0, st, a, B);
+        else hipLaunchKernelGGL((tq_ksmogn_il2m_wide_kernel<K, false>), grid, block, 0, st, a, B);
+      }
       return launch_status("tq_ksmogn_il2m_kernel");
     }
     if (bwd) hipLaunchKernelGGL((tq_ksmogn_il_kernel<K, ONE, true>), grid, block, 0, st, a, B);

@@ -80,11 +80,15 @@ TQ_HD void tq_combo0_prepare(float b, float rg, float g, float ln_g, TqCombo0* c
 // of the (concave, or decreasing when alpha < 1) function (alpha-1) ln v - beta v, v* = mu - g:
 //   v_s = clamp(mu - g, v_lo, v_hi),   v_hi = D - min_o delta_o,   v_lo = smallest positive v_o
 // so that the terms
-//   t_o = exp2[ (alpha-1) (log2(v_o / v_hi) - log2(v_s / v_hi)) + db_o ],
+//   t_o = exp2[ (alpha-1) (log2(v_o / v_hi) - log2(v_s / v_hi)) - (beta / ln 2) (v_hi - v_s) + db_o ],
 //   db_o = log2(w_o / w_max) + (beta / ln 2) (delta_o - delta_min)        (a per-offset constant)
-// neither overflow (db_o <= beta (delta_max - delta_min) / ln 2) nor all underflow, and
+// = (w_o / w_max) f(v_o) / f(v_s) with f(v) = v^(alpha-1) exp(-beta v) neither overflow (f(v_o) <= f(v_s)) nor all
+// underflow, and
 //   log p = [ -ln v_s + alpha phi(v_s / mu) + (1/2) ln alpha - ln sqrt(2 pi) - S(alpha) ]     (Binet form, see above)
-//           + ln w_max + beta (v_s - v_hi) + ln sum_o t_o.
+//           + ln w_max + ln sum_o t_o.
+// (Until round 3 the constant -beta (v_hi - v_s) stood outside the sum: exp2(db_o) alone reaches 2^(beta (delta_max -
+// delta_min) / ln 2), past the range of float32 once (delta_max - delta_min) / gain > 88 -- a 260-count histogram with the
+// gain fitted down to 2.9: d/d gain = -inf for a few units, every parameter NaN two steps later.)
 // Per (offset, combination) that is one fma, one add, one exp2 and three accumulations
 // (sum t, sum t log2(v_o / v_hi), sum t (delta_o - delta_min)); the log2 of v_o is shared by the combinations.
 //   d/dalpha = E_t[ln(v_o / mu)] + 1/(2 alpha) - S'(alpha),   E_t[v_o] = v_hi - E_t[delta_o - delta_min].
@@ -110,7 +114,7 @@ TQ_HD void tq_offset_info(const float* samples, const float* logits, int O, TqOf
 TQ_HD float tq_mo_reference(float mu, float g, float rg, float vlo, float vhi, float rvhi, float* a, float* c) {
   const float vs = fminf(fmaxf(mu - g, vlo), vhi);
   *a = mu * rg - 1.0f;
-  *c = -(*a) * TQ_FLOG2(vs * rvhi);
+  *c = -(*a) * TQ_FLOG2(vs * rvhi) - (rg * TQ_LOG2E) * (vhi - vs);
   return vs;
 }
 
@@ -127,7 +131,7 @@ TQ_HD void tq_mo_finish(bool fast, float mu, float vs, float vhi, float S0, floa
   const float lrho = TQ_FLOG(rho);
   const float rs = TQ_FRCP(S0);
   *lp = (alpha * (lrho + 1.0f - rho) - (lrho + TQ_FLOG(mu))) + 0.5f * lnalpha - TQ_LN_SQRT_2PI - S
-        + h.lw2max * TQ_LN2 + rg * (vs - vhi) + TQ_LN2 * TQ_FLOG2(S0);
+        + h.lw2max * TQ_LN2 + TQ_LN2 * TQ_FLOG2(S0);
   const float d = TQ_LN2 * (S1 * rs + TQ_FLOG2(vhi * rmu)) + 0.5f * ralpha - dS;
   *da = d;
   *gq = alpha * (d + 1.0f) - (vhi - S2 * rs) * rg;

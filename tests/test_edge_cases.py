@@ -126,6 +126,57 @@ def _clamped_height(device, lib):
         assert rel_err(got, ref) < 1e-4, (n, rel_err(got, ref))
 
 
+def _wide_histogram_small_gain(device, lib, il_min_units=None):
+    """An offset histogram 260 counts wide with the gain at 2.5: (delta_max - delta_min) / gain = 104 > 88, where the weights
+    exp(beta (delta_o - delta_min)) of the offset sum alone leave the range of float32.  The sum is taken relative to the
+    reference point INCLUDING its exp(-beta v) factor (tq_mo_reference); before that a fit with such a histogram, its gain
+    drifting down to 2.9, got d/d gain = -inf for a few units at step 3301 and NaN everywhere two steps later.  Every
+    likelihood and gradient row must be finite and agree with the oracle."""
+    from helpers import oracle_grads, rel_err
+
+    K, N, F = 2, 2, 6
+    d = make_dataset(N=N, F=F, K=K, offsets="wide")
+    d.images[:, :, 0] += 150.0  # bright tiles: the reference point lies far below the largest valid v
+    o = make_oracle(d, K)
+    with torch.no_grad():
+        o.params["gain_loc"].fill_(float(torch.tensor(2.5).log()))
+    eng = CosmosEngine(d, K=K, device=device, lib=lib)
+    if il_min_units is not None:
+        eng.il_min_units = il_min_units
+    oracle_to_engine(o, eng)
+    nd, fd = torch.arange(N), torch.arange(F)
+    lat32, base = fp32_latents(o, nd, fd)
+    assert float(lat32["gain"]) < 3.0
+    elbo_o, g_o = oracle_grads(o, nd, fd, base)
+    a = eng.make_args(None, None, draw_globals=False)
+    put_latents(eng, lat32, base)
+    for stage in GIVEN_STAGES:
+        eng.call(stage, a)
+    if eng.device.type == "cuda":
+        torch.cuda.synchronize()
+    B, M = N * F, 4
+    rows = eng.pix[: (M + 2 + 4 * K) * B].view(M + 2 + 4 * K, B).cpu()
+    assert bool(torch.isfinite(rows).all())
+    ll_o = o.last_terms["ll"].detach().reshape(M, B)
+    assert (rows[:M].double() - ll_o).abs().max() <= 1e-5 * ll_o.abs().max()
+    assert abs(float(eng.elbo_out[0]) - elbo_o) <= 2e-5 * abs(elbo_o)
+    gv = eng.named("grad")
+    for n, ref in g_o.items():
+        got = gv[n].cpu().double().reshape(ref.shape)
+        assert bool(torch.isfinite(got).all()), n
+        assert rel_err(got, ref) < 2e-4, (n, rel_err(got, ref))
+
+
+def test_wide_histogram_small_gain_host_math():
+    _wide_histogram_small_gain("cpu", load_hostcheck())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("il", [None, 1])
+def test_wide_histogram_small_gain_hip(il):
+    _wide_histogram_small_gain("cuda:0", None, il_min_units=il)
+
+
 def test_height_draw_on_the_clamp_host_math():
     _clamped_height("cpu", load_hostcheck())
 
