@@ -8,7 +8,10 @@ from tapqir_amd.utils.simulate import TEST_PARAMS, simulate
 dev = torch.device("cuda", 0)
 KK = int(os.environ.get("K", 2))
 class _M: K, device = KK, dev
-data = simulate(_M, 400, 1000, 1, 14, seed=1000, params=TEST_PARAMS)
+XT = os.environ.get("MODEL") == "crosstalk"
+NA, NF = int(os.environ.get("AOIS", 400)), int(os.environ.get("FRAMES", 1000))
+data = simulate(_M, NA, NF, 2 if XT else 1, int(os.environ.get("P", 14)), seed=1000,
+                params=dict(TEST_PARAMS, alpha=[[0.9, 0.1], [0.2, 0.8]]) if XT else TEST_PARAMS)
 s_ = torch.arange(70.0, 120.0)
 w_ = torch.minimum(s_ - 69.0, 120.0 - s_)
 if os.environ.get("OFFSETS") == "wide":  # offsets reaching above the dimmest pixels: masked offsets in most pixels' loops
@@ -17,15 +20,22 @@ if os.environ.get("OFFSETS") == "wide":  # offsets reaching above the dimmest pi
     data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s_, offset_weights=(w_ / w_.sum()).float())
 elif os.environ.get("OFFSETS", "hist") == "hist":
     data = CosmosDataset(data.images, data.xy, data.is_ontarget, offset_samples=s_, offset_weights=w_ / w_.sum())
-h = CosmosEngine(data, K=KK, device=dev, seed=int(os.environ.get("SEED", 7)))
-h.layout.set_constrained(h.params, initial_values(h, data))
+h = CosmosEngine(data, K=KK, device=dev, seed=int(os.environ.get("SEED", 7)), crosstalk=XT)
+if XT:
+    from tapqir_amd.models.crosstalk import crosstalk_initial_values as xt_initial_values
+    h.layout.set_constrained(h.params, xt_initial_values(h, data))
+else:
+    h.layout.set_constrained(h.params, initial_values(h, data))
+FULL = os.environ.get("FULL") == "1"
 g = torch.Generator().manual_seed(0)
 steps, every = int(os.environ.get("STEPS", 20000)), int(os.environ.get("EVERY", 50))
 host_draw = os.environ.get("HOST_DRAW") == "1"
 prev = h.params.clone(); prev_m = h.exp_avg.clone(); prev_v = h.exp_avg_sq.clone()
 for it in range(steps):
-    if host_draw:
-        h.step(torch.randperm(400, generator=g)[:10], torch.randperm(1000, generator=g)[:512])
+    if FULL:
+        h.step()
+    elif host_draw or XT:
+        h.step(torch.randperm(NA, generator=g)[:10], torch.randperm(NF, generator=g)[:512])
     else:
         assert h.step_subsampled(10, 512, g)
     if it + 1 >= int(os.environ.get("DENSE_FROM", 10**9)):
